@@ -1,0 +1,59 @@
+/*
+ * matrix_eyes_hip_ops.h — kernel-level entry points of libmatrixeyes_hip.so.
+ *
+ * Not part of the drop-in boundary (matrix_eyes_hip.h is): these expose the individual HIP
+ * kernels so that parity tests can check each one against the CPU oracle and bench.py can time
+ * the dominant kernel against its roofline.  All pointers are DEVICE pointers; 16-bit operands
+ * are in the context's dtype (ME_DTYPE_F16 / ME_DTYPE_BF16); work is enqueued on the context's
+ * stream and not synchronised.
+ */
+#ifndef MATRIX_EYES_HIP_OPS_H
+#define MATRIX_EYES_HIP_OPS_H
+
+#include "matrix_eyes_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ME_ACT_NONE = 0, ME_ACT_GELU = 1, ME_ACT_RELU = 2 };
+
+/* Linear (vit.rs:60-62,74,120,122): out = act(A[M][K] . W[N][K]^T + bias); out16 and/or out32
+   [M][N].  tile_cfg -1 = automatic. */
+int32_t me_op_linear(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, const void* W16,
+                     const float* bias, void* out16, float* out32, int32_t act, int32_t tile_cfg);
+/* Block residual update (vit.rs:165-169): x[M][N] += gamma[n] * (A . W^T + bias)  in place. */
+int32_t me_op_linear_residual(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16,
+                              const void* W16, const float* bias, const float* gamma, float* x32,
+                              int32_t tile_cfg);
+/* Attention (vit.rs:58-75): qkv16 [windows*tokens][3*heads*64] -> out16 [windows*tokens][heads*64] */
+int32_t me_op_attention(me_ctx* ctx, const void* qkv16, void* out16, int32_t windows, int32_t tokens,
+                        int32_t heads);
+/* LayerNorm (vit.rs:165,168,343): x32 [rows][dim] -> y16 and/or y32 */
+int32_t me_op_layernorm(me_ctx* ctx, const float* x32, const float* weight, const float* bias,
+                        void* y16, float* y32, int64_t rows, int32_t dim, float eps);
+/* Conv2d k x k (k in {1,3}, padding (k-1)/2, stride in {1,2}) as implicit GEMM.
+   in16b: zero-bordered NHWC [B][H+2][W+2][Cin]; w16: packed [Cout][k*k][Cin];
+   out32 [B*Ho*Wo][Cout] and/or out16 (zero-bordered [B][Ho+2][Wo+2][Cout] when border16);
+   res32/res32b optional f32 residuals [B*Ho*Wo][Cout]; act applies to out16 (and to out32 when
+   act_both). */
+int32_t me_op_conv2d(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const void* w16, int32_t Cout, int32_t k, int32_t stride, const float* bias,
+                     const float* res32, const float* res32b, float* out32, void* out16,
+                     int32_t border16, int32_t act, int32_t act_both, int32_t tile_cfg);
+/* ConvTranspose2d(2,2,stride 2): in16 NHWC [B*H*W][Cin]; w16 packed [(dy*2+dx)*Cout + co][Cin];
+   out32 [B][2H][2W][Cout] and/or out16 (zero-bordered when border16). */
+int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_t H, int32_t W,
+                                int32_t Cin, const void* w16, int32_t Cout, const float* bias,
+                                float* out32, void* out16, int32_t border16, int32_t tile_cfg);
+/* f32 <-> context 16-bit type */
+int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
+int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);
+/* Names of the GEMM tile configurations (for reports). */
+int32_t me_op_gemm_config_count(void);
+const char* me_op_gemm_config_name(int32_t cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATRIX_EYES_HIP_OPS_H */

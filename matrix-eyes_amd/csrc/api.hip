@@ -1,0 +1,617 @@
+// extern "C" boundary of libmatrixeyes_hip.so (include/matrix_eyes_hip.h, matrix_eyes_hip_ops.h).
+// Every entry point converts internal me::Error into a status code + last_error text; nothing
+// throws or aborts across the boundary.
+#include <cmath>
+#include <cstring>
+#include <exception>
+
+#include "../../include/matrix_eyes_hip_ops.h"
+#include "model.h"
+
+using namespace me;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct OutBuf {
+    void* dev = nullptr;
+    void* user = nullptr;
+    size_t bytes = 0;
+    bool staged = false;
+};
+
+OutBuf out_buf(me_ctx* ctx, void* user, size_t bytes, const std::string& name) {
+    OutBuf o;
+    o.user = user, o.bytes = bytes;
+    if (is_device_ptr(user)) {
+        o.dev = user;
+    } else {
+        o.dev = site_buf(ctx, name, bytes);
+        o.staged = true;
+    }
+    return o;
+}
+
+void finish(me_ctx* ctx, const OutBuf& o) {
+    if (o.staged) from_device(ctx, o.user, o.dev, o.bytes);
+}
+
+void check_ready(me_ctx* ctx) {
+    ME_CHECK(ctx->finalized, ME_ERR_NOT_READY,
+             "weights are not finalized (me_weights_finalize / me_bcast_weights)");
+}
+
+void check_batch(int32_t batch) {
+    ME_CHECK(batch >= 1 && batch <= 64, ME_ERR_BAD_SHAPE, "batch %d out of range [1, 64]", batch);
+}
+
+void validate_config(const me_model_config& c) {
+    ME_CHECK(c.grid >= 8 && c.grid % 8 == 0 && c.grid <= 64, ME_ERR_BAD_SHAPE,
+             "grid %d: need a multiple of 8 in [8, 64]", c.grid);
+    ME_CHECK(c.embed_dim == 64 * c.num_heads && c.num_heads >= 1, ME_ERR_BAD_SHAPE,
+             "embed_dim %d must be 64 * num_heads (%d)", c.embed_dim, c.num_heads);
+    ME_CHECK(c.embed_dim == 64 || c.embed_dim == 128 || c.embed_dim == 256 || c.embed_dim == 512 ||
+                 c.embed_dim == 1024,
+             ME_ERR_BAD_SHAPE, "embed_dim %d not in {64,128,256,512,1024}", c.embed_dim);
+    ME_CHECK(c.depth >= 1 && c.depth <= 64, ME_ERR_BAD_SHAPE, "depth %d", c.depth);
+    // vit.rs:318-324: a requested tap that does not exist panics
+    ME_CHECK(c.tap_blocks[0] >= 0 && c.tap_blocks[0] < c.depth && c.tap_blocks[1] >= 0 &&
+                 c.tap_blocks[1] < c.depth && c.tap_blocks[0] != c.tap_blocks[1],
+             ME_ERR_BAD_SHAPE, "tap blocks {%d,%d} with depth %d", c.tap_blocks[0], c.tap_blocks[1],
+             c.depth);
+    for (int i = 0; i < 4; ++i)
+        ME_CHECK(c.enc_dims[i] > 0 && c.enc_dims[i] % 64 == 0, ME_ERR_BAD_SHAPE,
+                 "enc_dims[%d] = %d must be a multiple of 64", i, c.enc_dims[i]);
+    ME_CHECK(c.dec_dim > 0 && c.dec_dim % 256 == 0, ME_ERR_BAD_SHAPE,
+             "dec_dim %d must be a multiple of 256", c.dec_dim);
+    ME_CHECK(c.head_dims[0] > 0 && c.head_dims[0] <= 32 && c.head_dims[0] % 4 == 0 &&
+                 c.head_dims[1] == 1,
+             ME_ERR_BAD_SHAPE, "head_dims {%d,%d}: need {<=32 multiple of 4, 1}", c.head_dims[0],
+             c.head_dims[1]);
+    ME_CHECK(c.ln_eps > 0.f, ME_ERR_BAD_ARG, "ln_eps %g", (double)c.ln_eps);
+}
+
+}  // namespace
+
+#define ME_API_BEGIN(ctx)                                                      \
+    if (!(ctx)) return ME_ERR_BAD_ARG;                                         \
+    try {                                                                      \
+        ME_HIP(hipSetDevice((ctx)->device));
+
+#define ME_API_END(ctx)                                                        \
+    }                                                                          \
+    catch (const me::Error& e) {                                               \
+        (ctx)->last_error = e.msg;                                             \
+        return e.code;                                                         \
+    }                                                                          \
+    catch (const std::exception& e) {                                          \
+        (ctx)->last_error = std::string("internal: ") + e.what();              \
+        return ME_ERR_BAD_ARG;                                                 \
+    }                                                                          \
+    return ME_OK;
+
+extern "C" {
+
+int32_t me_abi_version(void) { return ME_ABI_VERSION; }
+
+int32_t me_default_config(me_model_config* cfg) {
+    if (!cfg) return ME_ERR_BAD_ARG;
+    // vit.rs:17-19,349-358; encoder.rs:227; mod.rs:262-263,308-311
+    cfg->grid = 24, cfg->embed_dim = 1024, cfg->num_heads = 16, cfg->depth = 24;
+    cfg->tap_blocks[0] = 5, cfg->tap_blocks[1] = 11;
+    cfg->enc_dims[0] = 256, cfg->enc_dims[1] = 512, cfg->enc_dims[2] = 1024, cfg->enc_dims[3] = 1024;
+    cfg->dec_dim = 256;
+    cfg->head_dims[0] = 32, cfg->head_dims[1] = 1;
+    cfg->ln_eps = 1e-5f;
+    cfg->align_corners = 1;
+    return ME_OK;
+}
+
+int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* cfg, me_ctx** out) {
+    if (!out) return ME_ERR_BAD_ARG;
+    *out = nullptr;
+    me_ctx* ctx = nullptr;
+    try {
+        ME_CHECK(dtype == ME_DTYPE_F16 || dtype == ME_DTYPE_BF16, ME_ERR_BAD_ARG, "bad dtype %d",
+                 dtype);
+        int ndev = 0;
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        ME_CHECK(e == hipSuccess && ndev > 0, ME_ERR_HIP,
+                 "no HIP device available (%s): this library has no CPU fallback",
+                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        ME_CHECK(device_id >= 0 && device_id < ndev, ME_ERR_BAD_ARG, "device %d of %d", device_id,
+                 ndev);
+        ctx = new me_ctx();
+        ctx->device = device_id;
+        ctx->dtype = dtype;
+        if (cfg)
+            ctx->cfg = *cfg;
+        else
+            me_default_config(&ctx->cfg);
+        validate_config(ctx->cfg);
+        ME_HIP(hipSetDevice(device_id));
+        ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
+        build_weight_table(ctx);
+        ME_HIP(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
+        resolve_weights(ctx);
+        *out = ctx;
+        return ME_OK;
+    } catch (const me::Error& e) {
+        g_create_error = e.msg;
+        if (ctx) me_ctx_destroy(ctx);
+        return e.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        if (ctx) me_ctx_destroy(ctx);
+        return ME_ERR_BAD_ARG;
+    }
+}
+
+void me_ctx_destroy(me_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (auto& kv : ctx->bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* me_last_error(const me_ctx* ctx) {
+    return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+int32_t me_ctx_set_progress(me_ctx* ctx, me_progress_fn fn, void* user) {
+    if (!ctx) return ME_ERR_BAD_ARG;
+    ctx->progress = fn, ctx->progress_user = user;
+    return ME_OK;
+}
+
+int32_t me_ctx_set_stream(me_ctx* ctx, void* hip_stream) {
+    ME_API_BEGIN(ctx)
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ME_API_END(ctx)
+}
+
+int32_t me_ctx_synchronize(me_ctx* ctx) {
+    ME_API_BEGIN(ctx)
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    ME_API_END(ctx)
+}
+
+// ---- weights ----------------------------------------------------------------------------
+int32_t me_load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight_dtype,
+                       const int64_t* dims, int32_t ndim) {
+    ME_API_BEGIN(ctx)
+    load_weight(ctx, name, data, weight_dtype, dims, ndim);
+    ME_API_END(ctx)
+}
+
+int32_t me_expected_weight_count(const me_ctx* ctx) { return ctx ? (int32_t)ctx->slots.size() : 0; }
+
+int32_t me_expected_weight(const me_ctx* ctx, int32_t index, const char** name, int64_t dims[4],
+                           int32_t* ndim) {
+    if (!ctx || index < 0 || index >= (int32_t)ctx->slots.size() || !name || !dims || !ndim)
+        return ME_ERR_BAD_ARG;
+    const WeightSlot& s = ctx->slots[index];
+    *name = s.name.c_str();
+    *ndim = (int32_t)s.dims.size();
+    for (int i = 0; i < 4; ++i) dims[i] = i < *ndim ? s.dims[i] : 1;
+    return ME_OK;
+}
+
+int32_t me_weights_finalize(me_ctx* ctx) {
+    ME_API_BEGIN(ctx)
+    finalize_weights(ctx);
+    ME_API_END(ctx)
+}
+
+int64_t me_weight_arena_bytes(const me_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
+
+// ---- forward passes ----------------------------------------------------------------------
+int32_t me_preprocess_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, float* img) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(rgb && img, ME_ERR_BAD_ARG, "me_preprocess_u8: null pointer");
+    check_batch(batch);
+    const int S = ctx->S();
+    const size_t npix = (size_t)batch * S * S;
+    const void* src = to_device(ctx, rgb, npix * 3, "io.rgb");
+    OutBuf o = out_buf(ctx, img, npix * 3 * 4, "io.img");
+    preprocess_u8_launch((const uint8_t*)src, (float*)o.dev, batch, S, ctx->stream);
+    finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+namespace {
+struct ApiTap {
+    me_ctx* ctx;
+    const int32_t* blocks;
+    int n;
+    float** dev;
+    size_t bytes;
+};
+void api_tap_fn(void* user, int index, const float* tokens) {
+    ApiTap* t = (ApiTap*)user;
+    for (int i = 0; i < t->n; ++i)
+        if (t->blocks[i] == index)
+            ME_HIP(hipMemcpyAsync(t->dev[i], tokens, t->bytes, hipMemcpyDeviceToDevice,
+                                  t->ctx->stream));
+}
+}  // namespace
+
+int32_t me_vit_forward_features(me_ctx* ctx, int32_t which_vit, const float* xs, int32_t windows,
+                                const int32_t* intermediate_blocks, int32_t n_intermediate,
+                                float* final_out, float* const* intermediate_out) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    ME_CHECK(which_vit >= 0 && which_vit <= 2, ME_ERR_BAD_ARG, "which_vit %d", which_vit);
+    ME_CHECK(xs && final_out, ME_ERR_BAD_ARG, "me_vit_forward_features: null pointer");
+    ME_CHECK(windows >= 1 && windows <= 4096, ME_ERR_BAD_SHAPE, "windows %d", windows);
+    ME_CHECK(n_intermediate >= 0 && n_intermediate <= 8 &&
+                 (n_intermediate == 0 || (intermediate_blocks && intermediate_out)),
+             ME_ERR_BAD_ARG, "bad intermediate block list");
+    for (int i = 0; i < n_intermediate; ++i)  // vit.rs:318-324 "only {} / {} blocks found"
+        ME_CHECK(intermediate_blocks[i] >= 0 && intermediate_blocks[i] < ctx->cfg.depth,
+                 ME_ERR_BAD_SHAPE, "only %d blocks, block %d requested", ctx->cfg.depth,
+                 intermediate_blocks[i]);
+    const int g = ctx->g(), P = ctx->P(), T = ctx->T(), C = ctx->C(), win = 16 * g;
+    const size_t in_elems = (size_t)windows * 3 * win * win;
+    const float* xs_dev = (const float*)to_device(ctx, xs, in_elems * 4, "api.vit.in");
+    void* xs16 = site_buf(ctx, "api.vit.in16", in_elems * 2);
+    cast_f32_to_16_launch(xs_dev, xs16, (int64_t)in_elems, ctx->dtype, ctx->stream);
+    void* patches = site_buf(ctx, "api.vit.patches", (size_t)windows * P * 768 * 2);
+    patchify_windows_launch(xs16, patches, windows, g, ctx->dtype, ctx->stream);
+    const size_t tok_bytes = (size_t)windows * T * C * 4;
+    std::vector<OutBuf> inter(n_intermediate);
+    std::vector<float*> inter_dev(n_intermediate);
+    for (int i = 0; i < n_intermediate; ++i) {
+        ME_CHECK(intermediate_out[i], ME_ERR_BAD_ARG, "null intermediate output %d", i);
+        inter[i] = out_buf(ctx, intermediate_out[i], tok_bytes, "api.vit.inter" + std::to_string(i));
+        inter_dev[i] = (float*)inter[i].dev;
+    }
+    ApiTap tap{ctx, intermediate_blocks, n_intermediate, inter_dev.data(), tok_bytes};
+    VitTaps taps;
+    if (n_intermediate) taps.fn = api_tap_fn, taps.user = &tap;
+    OutBuf fin = out_buf(ctx, final_out, tok_bytes, "api.vit.final");
+    vit_forward(ctx, which_vit, patches, windows, taps, nullptr, (float*)fin.dev, "vit.api",
+                ctx->stream);
+    finish(ctx, fin);
+    for (auto& o : inter) finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+int32_t me_encoder_forward_encodings(me_ctx* ctx, const float* x, int32_t batch,
+                                     float* const encodings[5]) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(x && encodings, ME_ERR_BAD_ARG, "me_encoder_forward_encodings: null pointer");
+    for (int i = 0; i < 5; ++i) ME_CHECK(encodings[i], ME_ERR_BAD_ARG, "null encoding %d", i);
+    const me_model_config& c = ctx->cfg;
+    const int S = ctx->S(), g = ctx->g();
+    const float* x_dev = (const float*)to_device(ctx, x, (size_t)batch * 3 * S * S * 4, "io.img");
+    stage_encoder(ctx, x_dev, batch);
+    const int H[5] = {32 * g, 16 * g, 8 * g, 4 * g, 2 * g};
+    const int Cc[5] = {c.dec_dim, c.enc_dims[0], c.enc_dims[1], c.enc_dims[2], c.enc_dims[3]};
+    const char* names[5] = {"enc0.f32", "enc1.16b", "enc2.16b", "enc3.16b", "enc4.16b"};
+    for (int i = 0; i < 5; ++i) {
+        OutBuf o = out_buf(ctx, encodings[i], (size_t)batch * Cc[i] * H[i] * H[i] * 4,
+                           "api.enc.out" + std::to_string(i));
+        if (i == 0)
+            nhwc32_to_nchw32_launch((const float*)ctx->bufs.at(names[i]).p, (float*)o.dev, batch, H[i],
+                                    H[i], Cc[i], ctx->stream);
+        else
+            nhwc16_to_nchw32_launch(ctx->bufs.at(names[i]).p, (float*)o.dev, batch, H[i], H[i], Cc[i],
+                                    1, ctx->dtype, ctx->stream);
+        finish(ctx, o);
+    }
+    ME_API_END(ctx)
+}
+
+int32_t me_decoder_forward(me_ctx* ctx, const float* const encodings[5], int32_t batch,
+                           float* features, float* lowres_features) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(encodings && features && lowres_features, ME_ERR_BAD_ARG,
+             "me_decoder_forward: null pointer");
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), dec = c.dec_dim;
+    const int H[5] = {32 * g, 16 * g, 8 * g, 4 * g, 2 * g};
+    const int Cc[5] = {dec, c.enc_dims[0], c.enc_dims[1], c.enc_dims[2], c.enc_dims[3]};
+    const char* names[5] = {"enc0.r16b", "enc1.16b", "enc2.16b", "enc3.16b", "enc4.16b"};
+    for (int i = 0; i < 5; ++i) {
+        ME_CHECK(encodings[i], ME_ERR_BAD_ARG, "null encoding %d", i);
+        const size_t n = (size_t)batch * Cc[i] * H[i] * H[i];
+        const float* src =
+            (const float*)to_device(ctx, encodings[i], n * 4, "api.dec.in" + std::to_string(i));
+        void* d16 = site_buf(ctx, names[i], (size_t)batch * (H[i] + 2) * (H[i] + 2) * Cc[i] * 2);
+        float* d32 = i == 0 ? (float*)site_buf(ctx, "enc0.f32", n * 4) : nullptr;
+        nchw32_to_nhwc_launch(src, d32, d16, batch, H[i], H[i], Cc[i], 1, i == 0 ? 1 : 0, ctx->dtype,
+                              ctx->stream);
+    }
+    stage_decoder(ctx, batch, true);
+    OutBuf of = out_buf(ctx, features, (size_t)batch * dec * H[0] * H[0] * 4, "api.dec.feat");
+    nhwc32_to_nchw32_launch((const float*)ctx->bufs.at("features.f32").p, (float*)of.dev, batch, H[0],
+                            H[0], dec, ctx->stream);
+    finish(ctx, of);
+    OutBuf ol = out_buf(ctx, lowres_features, (size_t)batch * dec * H[4] * H[4] * 4, "api.dec.low");
+    nhwc32_to_nchw32_launch((const float*)ctx->bufs.at("lowres.f32").p, (float*)ol.dev, batch, H[4],
+                            H[4], dec, ctx->stream);
+    finish(ctx, ol);
+    ME_API_END(ctx)
+}
+
+int32_t me_head_forward(me_ctx* ctx, const float* features, int32_t batch,
+                        float* canonical_inverse_depth) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(features && canonical_inverse_depth, ME_ERR_BAD_ARG, "me_head_forward: null pointer");
+    const int S = ctx->S(), Hh = S / 2, dec = ctx->cfg.dec_dim;
+    const size_t n = (size_t)batch * dec * Hh * Hh;
+    const float* src = (const float*)to_device(ctx, features, n * 4, "api.head.in");
+    void* f16b = site_buf(ctx, "features.16b", (size_t)batch * (Hh + 2) * (Hh + 2) * dec * 2);
+    nchw32_to_nhwc_launch(src, nullptr, f16b, batch, Hh, Hh, dec, 1, 0, ctx->dtype, ctx->stream);
+    OutBuf o = out_buf(ctx, canonical_inverse_depth, (size_t)batch * S * S * 4, "io.depth");
+    stage_head(ctx, batch, nullptr, false, (float*)o.dev);
+    finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+int32_t me_fov_forward(me_ctx* ctx, const float* x, const float* lowres_feature, int32_t batch,
+                       float* fov_deg) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(x && lowres_feature && fov_deg, ME_ERR_BAD_ARG, "me_fov_forward: null pointer");
+    const int S = ctx->S(), g = ctx->g(), dec = ctx->cfg.dec_dim;
+    const float* x_dev = (const float*)to_device(ctx, x, (size_t)batch * 3 * S * S * 4, "io.img");
+    void* x2 = site_buf(ctx, "enc.x2", (size_t)batch * 3 * (S / 4) * (S / 4) * 2);
+    bilinear_launch(x_dev, x2, 3 * batch, S, S / 4, ctx->cfg.align_corners, ctx->dtype, ctx->stream);
+    const size_t nl = (size_t)batch * dec * 4 * g * g;
+    const float* low = (const float*)to_device(ctx, lowres_feature, nl * 4, "api.fov.low");
+    float* low32 = (float*)site_buf(ctx, "lowres.f32", nl * 4);
+    nchw32_to_nhwc_launch(low, low32, nullptr, batch, 2 * g, 2 * g, dec, 0, 0, ctx->dtype, ctx->stream);
+    OutBuf o = out_buf(ctx, fov_deg, (size_t)batch * 4, "fov_deg");
+    stage_fov(ctx, batch, (float*)o.dev);
+    finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+namespace {
+void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const float* f_norm,
+                        float* inverse_depth, float* fov_deg_out) {
+    const int S = ctx->S();
+    stage_encoder(ctx, img_dev, batch);
+    stage_decoder(ctx, batch, false);
+    float* fnorm_dev = (float*)site_buf(ctx, "f_norm", (size_t)batch * 4);
+    OutBuf ofov;
+    if (f_norm) {
+        if (is_device_ptr(f_norm))
+            ME_HIP(hipMemcpyAsync(fnorm_dev, f_norm, (size_t)batch * 4, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+        else
+            ME_HIP(hipMemcpyAsync(fnorm_dev, f_norm, (size_t)batch * 4, hipMemcpyHostToDevice,
+                                  ctx->stream));
+    } else {
+        // mod.rs:343-358
+        ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
+        stage_fov(ctx, batch, (float*)ofov.dev);
+    }
+    OutBuf o = out_buf(ctx, inverse_depth, (size_t)batch * S * S * 4, "io.depth");
+    stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev);
+    finish(ctx, o);
+    if (!f_norm && fov_deg_out) finish(ctx, ofov);
+    report(ctx, 1.0f, nullptr);
+}
+}  // namespace
+
+int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const float* f_norm,
+                         float* inverse_depth, float* fov_deg_out) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(img && inverse_depth, ME_ERR_BAD_ARG, "me_extract_depth: null pointer");
+    const int S = ctx->S();
+    const float* img_dev = (const float*)to_device(ctx, img, (size_t)batch * 3 * S * S * 4, "io.img");
+    extract_depth_impl(ctx, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    ME_API_END(ctx)
+}
+
+int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, const float* f_norm,
+                            float* inverse_depth, float* fov_deg_out) {
+    ME_API_BEGIN(ctx)
+    check_ready(ctx);
+    check_batch(batch);
+    ME_CHECK(rgb && inverse_depth, ME_ERR_BAD_ARG, "me_extract_depth_u8: null pointer");
+    const int S = ctx->S();
+    const size_t npix = (size_t)batch * S * S;
+    const void* src = to_device(ctx, rgb, npix * 3, "io.rgb");
+    float* img_dev = (float*)site_buf(ctx, "io.img", npix * 3 * 4);
+    preprocess_u8_launch((const uint8_t*)src, img_dev, batch, S, ctx->stream);
+    extract_depth_impl(ctx, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    ME_API_END(ctx)
+}
+
+// ---- output back end ---------------------------------------------------------------------
+int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* min_out,
+                              float* max_out) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(depth && count > 0, ME_ERR_BAD_ARG, "me_depth_clamp_minmax: bad argument");
+    const bool dev = is_device_ptr(depth);
+    float* d = dev ? depth : (float*)site_buf(ctx, "out.depth", (size_t)count * 4);
+    if (!dev) ME_HIP(hipMemcpyAsync(d, depth, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    float* mm = (float*)site_buf(ctx, "out.minmax", 8);
+    depth_clamp_minmax_launch(d, count, mm, ctx->stream);
+    float host[2];
+    ME_HIP(hipMemcpyAsync(host, mm, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!dev) ME_HIP(hipMemcpyAsync(depth, d, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    if (min_out) *min_out = host[0];
+    if (max_out) *max_out = host[1];
+    ME_API_END(ctx)
+}
+
+int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols, float min_depth,
+                      float max_depth, int32_t out_w, int32_t out_h, float amplitude,
+                      const uint8_t* noise, uint8_t* out) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(depth && noise && out, ME_ERR_BAD_ARG, "me_stereogram: null pointer");
+    ME_CHECK(rows > 0 && cols > 0 && out_w > 0 && out_h > 0, ME_ERR_BAD_SHAPE,
+             "me_stereogram: %dx%d -> %dx%d", rows, cols, out_w, out_h);
+    const size_t nout = (size_t)out_w * out_h * 3;
+    const float* d = (const float*)to_device(ctx, depth, (size_t)rows * cols * 4, "out.depth");
+    const uint8_t* nz = (const uint8_t*)to_device(ctx, noise, nout, "out.noise");
+    OutBuf o = out_buf(ctx, out, nout, "out.stereo");
+    stereogram_launch(d, rows, cols, min_depth, max_depth, out_w, out_h, amplitude, nz,
+                      (uint8_t*)o.dev, ctx->stream);
+    finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+int32_t me_depthmap_rgb(me_ctx* ctx, const float* depth, int64_t count, float min_depth,
+                        float max_depth, uint8_t* rgb) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(depth && rgb && count > 0, ME_ERR_BAD_ARG, "me_depthmap_rgb: bad argument");
+    const float* d = (const float*)to_device(ctx, depth, (size_t)count * 4, "out.depth");
+    OutBuf o = out_buf(ctx, rgb, (size_t)count * 3, "out.rgb");
+    depthmap_rgb_launch(d, count, min_depth, max_depth, (uint8_t*)o.dev, ctx->stream);
+    finish(ctx, o);
+    ME_API_END(ctx)
+}
+
+int32_t me_mesh_index(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
+                      int32_t* vertex_index, int64_t* nvertices, int64_t* nfaces, int32_t* faces) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(depth && vertex_index && nvertices && nfaces, ME_ERR_BAD_ARG,
+             "me_mesh_index: null pointer");
+    ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "me_mesh_index: %dx%d", width, height);
+    const size_t nv = (size_t)width * height;
+    const size_t nt = 2 * (size_t)(width - 1) * (height - 1);
+    const float* d = (const float*)to_device(ctx, depth, nv * 4, "out.depth");
+    OutBuf ov = out_buf(ctx, vertex_index, nv * 4, "out.vindex");
+    OutBuf of;
+    if (faces) of = out_buf(ctx, faces, nt * 3 * 4, "out.faces");
+    mesh_index_run(d, width, height, (int32_t*)ov.dev, faces ? (int32_t*)of.dev : nullptr, nvertices,
+                   nfaces, ctx->stream);
+    finish(ctx, ov);
+    if (faces && of.staged) {  // only the kept triangles are defined
+        ME_HIP(hipMemcpyAsync(faces, of.dev, (size_t)*nfaces * 12, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        ME_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ME_API_END(ctx)
+}
+
+int32_t me_mesh_vertices(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
+                         const int32_t* vertex_index, int64_t nvertices, uint32_t original_width,
+                         uint32_t original_height, float* uv, float* xyz) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(depth && vertex_index && nvertices >= 0, ME_ERR_BAD_ARG, "me_mesh_vertices: bad argument");
+    ME_CHECK(original_width > 0 && original_height > 0, ME_ERR_BAD_ARG, "original size 0");
+    const size_t nv = (size_t)width * height;
+    const float* d = (const float*)to_device(ctx, depth, nv * 4, "out.depth");
+    const int32_t* vi = (const int32_t*)to_device(ctx, vertex_index, nv * 4, "out.vindex");
+    // output.rs:222-225 (f32 division of the u32 sizes)
+    const uint32_t mx = original_width > original_height ? original_width : original_height;
+    const float xm = (float)original_width / (float)mx, ym = (float)original_height / (float)mx;
+    OutBuf ouv, oxyz;
+    if (uv) ouv = out_buf(ctx, uv, (size_t)nvertices * 8 + 8, "out.uv");
+    if (xyz) oxyz = out_buf(ctx, xyz, (size_t)nvertices * 12 + 12, "out.xyz");
+    mesh_vertices_launch(d, width, height, vi, xm, ym, uv ? (float*)ouv.dev : nullptr,
+                         xyz ? (float*)oxyz.dev : nullptr, ctx->stream);
+    if (uv && ouv.staged) from_device(ctx, uv, ouv.dev, (size_t)nvertices * 8);
+    if (xyz && oxyz.staged) from_device(ctx, xyz, oxyz.dev, (size_t)nvertices * 12);
+    ME_API_END(ctx)
+}
+
+// ---- kernel-level surface (matrix_eyes_hip_ops.h) -------------------------------------------
+int32_t me_op_linear(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, const void* W16,
+                     const float* bias, void* out16, float* out32, int32_t act, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16, p.bias = bias;
+    p.out16 = out16, p.out32 = out32, p.ldc = N, p.act = act;
+    gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_linear_residual(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16,
+                              const void* W16, const float* bias, const float* gamma, float* x32,
+                              int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(bias && gamma && x32, ME_ERR_BAD_ARG, "me_op_linear_residual: null pointer");
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16, p.bias = bias, p.gamma = gamma;
+    p.res32 = x32, p.out32 = x32, p.ldc = N;
+    gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_attention(me_ctx* ctx, const void* qkv16, void* out16, int32_t windows, int32_t tokens,
+                        int32_t heads) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(qkv16 && out16, ME_ERR_BAD_ARG, "me_op_attention: null pointer");
+    attention_launch(qkv16, out16, windows, tokens, heads, ctx->dtype, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_layernorm(me_ctx* ctx, const float* x32, const float* weight, const float* bias,
+                        void* y16, float* y32, int64_t rows, int32_t dim, float eps) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(x32 && weight && bias && (y16 || y32), ME_ERR_BAD_ARG, "me_op_layernorm: null pointer");
+    layernorm_launch(x32, weight, bias, y16, y32, rows, dim, eps, ctx->dtype, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_conv2d(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const void* w16, int32_t Cout, int32_t k, int32_t stride, const float* bias,
+                     const float* res32, const float* res32b, float* out32, void* out16,
+                     int32_t border16, int32_t act, int32_t act_both, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK((k == 1 || k == 3) && (stride == 1 || stride == 2), ME_ERR_BAD_SHAPE,
+             "me_op_conv2d: k=%d stride=%d", k, stride);
+    GemmParams p = GemmParams();
+    const int Ho = H / stride, Wo = W / stride;
+    p.M = B * Ho * Wo, p.N = Cout, p.K = k * k * Cin, p.A = in16b;
+    p.in_Hp = H + 2, p.in_Wp = W + 2, p.Cin = Cin, p.out_H = Ho, p.out_W = Wo;
+    p.KH = k, p.KW = k, p.stride = stride, p.W = w16, p.bias = bias;
+    p.res32 = res32, p.res32b = res32b, p.out32 = out32, p.out16 = out16, p.ldc = Cout;
+    p.out16_border = border16, p.act = act, p.act16_only = act_both ? 0 : 1;
+    gemm_launch(p, A_CONV, EPI_STORE, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_t H, int32_t W,
+                                int32_t Cin, const void* w16, int32_t Cout, const float* bias,
+                                float* out32, void* out16, int32_t border16, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    GemmParams p = GemmParams();
+    p.M = B * H * W, p.N = 4 * Cout, p.K = Cin, p.A = in16, p.lda = Cin, p.W = w16, p.bias = bias;
+    p.out_H = H, p.out_W = W, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
+    p.out16_border = border16, p.ldc = Cout;
+    gemm_launch(p, A_PLAIN, EPI_CONVT, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count) {
+    ME_API_BEGIN(ctx)
+    cast_f32_to_16_launch(src, dst16, count, ctx->dtype, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count) {
+    ME_API_BEGIN(ctx)
+    cast_16_to_f32_launch(src16, dst, count, ctx->dtype, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_gemm_config_count(void) { return gemm_num_configs(); }
+const char* me_op_gemm_config_name(int32_t cfg) { return gemm_config_name(cfg); }
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+// Internal declarations shared by the HIP translation units of libmatrixeyes_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/matrix_eyes_hip.h"
+
+namespace me {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((__vector_size__(8)));
+
+struct Status {
+    int32_t code = ME_OK;
+    std::string msg;
+};
+
+// Thrown inside the library, caught at the C ABI; nothing escapes to the caller.
+struct Error {
+    int32_t code;
+    std::string msg;
+};
+
+[[noreturn]] void fail(int32_t code, const char* fmt, ...);
+
+#define ME_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            ::me::fail(e__ == hipErrorOutOfMemory ? ME_ERR_OOM : ME_ERR_HIP, "%s: %s (%s:%d)", \
+                       #expr, hipGetErrorString(e__), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define ME_CHECK(cond, code, ...)                   \
+    do {                                            \
+        if (!(cond)) ::me::fail((code), __VA_ARGS__); \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution: D[m][n] = sum_k A(m,k) * W[n][k]  (+ epilogue).
+// W is always row-major [N][K], K contiguous (the PyTorch Linear layout; conv weights are
+// repacked to [Cout][tap][Cin] at load time).
+// ---------------------------------------------------------------------------------------
+enum AMode : int32_t {
+    A_PLAIN = 0,  // A row-major [M][lda]
+    A_CONV = 1    // A gathered from a zero-bordered NHWC map: row m = (b,y,x), k = (tap, cin)
+};
+
+enum EpiKind : int32_t {
+    EPI_STORE = 0,       // out32 [M][ldc] / out16 (row-major, or pixels of a zero-bordered NHWC
+                         // map when out16_border) = act(acc + bias + res32 + res32b)
+    EPI_RESID_SCALE = 1, // out32[m][n] = res32[m][n] + gamma[n]*(acc + bias[n])  (ViT proj / fc2)
+    EPI_PATCH_EMBED = 2, // out32[(m/P)*(P+1) + 1 + m%P][n] = acc + bias[n] + pos[1 + m%P][n]
+    EPI_CONVT = 4,       // ConvTranspose2d(2,2,s2) pixel shuffle: n = (dy*2+dx)*Cout + co
+    EPI_HEAD_FINAL = 5   // relu(acc+bias) . w2 + b2 -> relu -> / f_norm -> clamp  (N <= 32)
+};
+
+enum Act : int32_t { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+struct GemmParams {
+    // problem
+    int32_t M, N, K;
+    // A operand
+    const void* A;     // f16/bf16
+    int64_t lda;       // elements (A_PLAIN)
+    // A_CONV geometry: input map [B][Hp][Wp][Cin] with Hp = Hin + 2, Wp = Win + 2 (zero border)
+    int32_t in_Hp, in_Wp, Cin;
+    int32_t out_H, out_W;     // output pixels per image: M = B * out_H * out_W
+    int32_t KH, KW, stride;   // 1x1 or 3x3 (pad (KH-1)/2); stride 1 or 2
+    // W operand
+    const void* W;     // [N][K]
+    // epilogue
+    const float* bias;     // [N] or [Cout] (EPI_CONVT) or null
+    const float* gamma;    // EPI_RESID_SCALE
+    const float* res32;    // optional f32 residual, same row mapping as out32
+    const float* res32b;   // optional second f32 residual
+    const float* pos;      // EPI_PATCH_EMBED: pos_embed [P+1][N]
+    float* out32;          // optional f32 output
+    void* out16;           // optional f16/bf16 output
+    int64_t ldc;           // row stride (elements) of out32/out16/res32 for row-major outputs
+    int32_t act;           // activation applied to the f16 output (and f32 for EPI_STORE)
+    int32_t act16_only;    // 1: activation only on the out16 copy (out32 stays raw)
+    int32_t out16_border;  // EPI_STORE/EPI_CONVT: out16 is zero-bordered [B][out_H+2][out_W+2][C]
+    int32_t tokens_per_window;  // EPI_PATCH_EMBED: P
+    int32_t Cout;          // EPI_CONVT: N = 4*Cout
+    // EPI_HEAD_FINAL
+    const float* w2;       // [N]
+    const float* b2;       // device scalar
+    const float* f_norm;   // device [B] (one per image) or null (= 1): out32[m] = clamp(v / f_norm[b])
+    float clamp_lo, clamp_hi;  // mod.rs:362 clamp(1e-4, 1e4); +-inf for the canonical head output
+    int32_t pixels_per_image;
+};
+
+// dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).
+void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
+                 int32_t force_cfg = -1);
+int gemm_num_configs();
+const char* gemm_config_name(int cfg);
+
+// ---------------------------------------------------------------------------------------
+// Attention: qkv [rows][3*C] (q | k | v, each [heads][64]), rows = windows * tokens;
+// out [rows][C].  softmax(q*scale . k^T) v per (window, head); head_dim is 64.
+// ---------------------------------------------------------------------------------------
+void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
+                      int32_t dtype, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Row-wise and layout kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------
+// y16[r][:] = (x[r][:] - mean) / sqrt(var + eps) * w + b ; optional f32 copy y32.
+void layernorm_launch(const float* x, const float* w, const float* b, void* y16, float* y32,
+                      int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream);
+// u8 HWC -> f32 NCHW, reconstruction.rs:114-124
+void preprocess_u8_launch(const uint8_t* rgb, float* img, int32_t batch, int32_t size,
+                          hipStream_t stream);
+// f32 NCHW -> f16 NCHW (same layout)
+void cast_f32_to_16_launch(const float* src, void* dst, int64_t count, int32_t dtype,
+                           hipStream_t stream);
+void cast_16_to_f32_launch(const void* src, float* dst, int64_t count, int32_t dtype,
+                           hipStream_t stream);
+// bilinear resample of f32 planes [planes][in][in] -> 16-bit [planes][out][out] (encoder.rs:125-140)
+void bilinear_launch(const float* src32, void* dst16, int32_t planes, int32_t in_size,
+                     int32_t out_size, int32_t align_corners, int32_t dtype, hipStream_t stream);
+// windows of the three pyramid levels -> patch matrix [(B*35)*g*g][3*256]; window order is
+// image-major here: row = ((b*35 + win)*g*g + patch)
+void patchify_launch(const void* x0, const void* x1, const void* x2, void* patches, int32_t batch,
+                     int32_t grid, int32_t dtype, hipStream_t stream);
+// one planar image stack [W][3][16g][16g] -> patch matrix [W*g*g][768]
+void patchify_windows_launch(const void* xs16, void* patches, int32_t windows, int32_t grid,
+                             int32_t dtype, hipStream_t stream);
+// cls rows: tokens[w*(P+1)][:] = cls + pos[0]
+void cls_rows_launch(float* tokens, const float* cls, const float* pos, int32_t windows,
+                     int32_t tokens_per_window, int32_t dim, hipStream_t stream);
+// encoder.rs:158-208 reshape_feature + merge: token rows of `steps*steps` windows (first window
+// index win0 of each image's 35) -> NHWC f16 map [B][side][side][C], side = merged size.
+// src is f32 tokens (src32) or f16 tokens (src16) with rows (b*35+win)*(P+1) + 1 + patch.
+void merge_launch(const float* src32, const void* src16, void* dst16, int32_t batch,
+                  int32_t windows_per_image, int32_t win0, int32_t steps, int32_t padding,
+                  int32_t grid, int32_t dim, int32_t dtype, hipStream_t stream);
+// NHWC (f16 or f32, optional zero border) <-> NCHW f32
+void nhwc16_to_nchw32_launch(const void* src16, float* dst, int32_t batch, int32_t H, int32_t W,
+                             int32_t C, int32_t border, int32_t dtype, hipStream_t stream);
+void nhwc32_to_nchw32_launch(const float* src, float* dst, int32_t batch, int32_t H, int32_t W,
+                             int32_t C, hipStream_t stream);
+// NCHW f32 -> NHWC: optional f32 copy, optional f16 copy (zero border, optional relu)
+void nchw32_to_nhwc_launch(const float* src, float* dst32, void* dst16, int32_t batch, int32_t H,
+                           int32_t W, int32_t C, int32_t border, int32_t relu16, int32_t dtype,
+                           hipStream_t stream);
+// NHWC f32 -> 16-bit NHWC with a zero border (optional relu)
+void nhwc32_to_16b_launch(const float* src, void* dst16b, int32_t batch, int32_t H, int32_t W,
+                          int32_t C, int32_t relu, int32_t dtype, hipStream_t stream);
+// channel concat of two NHWC f16 maps
+void concat_channels_launch(const void* a, const void* b, void* dst, int64_t pixels, int32_t Ca,
+                            int32_t Cb, hipStream_t stream);
+// FOV tail (fov.rs:67-87)
+void fov_add_relu_launch(const float* lin /*[B][P][C] tokens (cls dropped by caller offset)*/,
+                         const float* low /*NHWC f32 [B][g][g][C]*/, void* dst16 /*bordered*/,
+                         int32_t batch, int32_t grid, int32_t C, int32_t tokens_per_window,
+                         int32_t dtype, hipStream_t stream);
+void fov_final_launch(const void* x16 /*NHWC [B][k][k][C]*/, const float* w /*[k][k][C]*/,
+                      const float* bias, float* fov_deg, float* f_norm, int32_t batch, int32_t k,
+                      int32_t C, int32_t dtype, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Output back end (output.hip)
+// ---------------------------------------------------------------------------------------
+void depth_clamp_minmax_launch(float* depth, int64_t count, float* minmax_dev /*[2]*/,
+                               hipStream_t stream);
+void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min_depth,
+                       float max_depth, int32_t out_w, int32_t out_h, float amplitude,
+                       const uint8_t* noise, uint8_t* out, hipStream_t stream);
+void depthmap_rgb_launch(const float* depth, int64_t count, float min_depth, float max_depth,
+                         uint8_t* rgb, hipStream_t stream);
+// synchronises the stream (the counts come back to the host)
+void mesh_index_run(const float* depth_dev, int32_t width, int32_t height, int32_t* vertex_index_dev,
+                    int32_t* faces_dev /*nullable*/, int64_t* nverts, int64_t* nfaces,
+                    hipStream_t stream);
+void mesh_vertices_launch(const float* depth, int32_t width, int32_t height,
+                          const int32_t* vertex_index, float xm, float ym, float* uv, float* xyz,
+                          hipStream_t stream);
+
+}  // namespace me

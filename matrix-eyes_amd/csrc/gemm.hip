@@ -1,0 +1,97 @@
+// Tile-configuration choice and (dtype, A-mode, epilogue) dispatch for the GEMM core.
+#include <cstdarg>
+#include <cstdio>
+
+#include "gemm_core.h"
+
+namespace me {
+
+void fail(int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error{code, buf};
+}
+
+// explicit specialisations live in gemm_{f16,bf16}_{plain,conv}.hip
+#define ME_DECL(T, A, E) \
+    template <>          \
+    void gemm_dispatch<T, A, E>(const GemmParams&, int, hipStream_t);
+ME_DECL(f16, A_PLAIN, EPI_STORE)
+ME_DECL(f16, A_PLAIN, EPI_RESID_SCALE)
+ME_DECL(f16, A_PLAIN, EPI_PATCH_EMBED)
+ME_DECL(f16, A_PLAIN, EPI_CONVT)
+ME_DECL(f16, A_CONV, EPI_STORE)
+ME_DECL(f16, A_CONV, EPI_HEAD_FINAL)
+ME_DECL(bf16, A_PLAIN, EPI_STORE)
+ME_DECL(bf16, A_PLAIN, EPI_RESID_SCALE)
+ME_DECL(bf16, A_PLAIN, EPI_PATCH_EMBED)
+ME_DECL(bf16, A_PLAIN, EPI_CONVT)
+ME_DECL(bf16, A_CONV, EPI_STORE)
+ME_DECL(bf16, A_CONV, EPI_HEAD_FINAL)
+#undef ME_DECL
+
+static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w"};
+int gemm_num_configs() { return 4; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 4 ? kCfgNames[cfg] : "?"; }
+
+// 256 CUs; the large tiles run one workgroup per CU, so they want >= ~1.5 full rounds.
+static int pick_config(int64_t M, int64_t N) {
+    const int64_t t0 = cdiv(M, 256) * cdiv(N, 256);
+    if (N >= 256 && t0 >= 400) return 0;
+    const int64_t t3 = cdiv(M, 256) * cdiv(N, 128);
+    if (N >= 128 && t3 >= 300) return 3;
+    const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
+    if (N >= 128 && t1 >= 128) return 1;
+    return 2;
+}
+
+template <typename T>
+static void launch_typed(const GemmParams& p, AMode amode, EpiKind epi, int cfg, hipStream_t s) {
+    if (amode == A_PLAIN) {
+        switch (epi) {
+            case EPI_STORE: gemm_dispatch<T, A_PLAIN, EPI_STORE>(p, cfg, s); return;
+            case EPI_RESID_SCALE: gemm_dispatch<T, A_PLAIN, EPI_RESID_SCALE>(p, cfg, s); return;
+            case EPI_PATCH_EMBED: gemm_dispatch<T, A_PLAIN, EPI_PATCH_EMBED>(p, cfg, s); return;
+            case EPI_CONVT: gemm_dispatch<T, A_PLAIN, EPI_CONVT>(p, cfg, s); return;
+            default: break;
+        }
+    } else {
+        switch (epi) {
+            case EPI_STORE: gemm_dispatch<T, A_CONV, EPI_STORE>(p, cfg, s); return;
+            case EPI_HEAD_FINAL: gemm_dispatch<T, A_CONV, EPI_HEAD_FINAL>(p, cfg, s); return;
+            default: break;
+        }
+    }
+    fail(ME_ERR_BAD_ARG, "gemm: unsupported (A-mode %d, epilogue %d)", (int)amode, (int)epi);
+}
+
+void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
+                 int32_t force_cfg) {
+    ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
+             p.N, p.K);
+    ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);
+    ME_CHECK(p.N % 4 == 0, ME_ERR_BAD_SHAPE, "gemm: N=%d is not a multiple of 4", p.N);
+    ME_CHECK(p.A && p.W, ME_ERR_BAD_ARG, "gemm: null operand");
+    if (amode == A_CONV) {
+        ME_CHECK(p.Cin % 64 == 0 && p.K == p.KH * p.KW * p.Cin, ME_ERR_BAD_SHAPE,
+                 "conv: Cin=%d K=%d KHxKW=%dx%d", p.Cin, p.K, p.KH, p.KW);
+        ME_CHECK(p.out_H > 0 && p.out_W > 0 && p.M % (p.out_H * p.out_W) == 0, ME_ERR_BAD_SHAPE,
+                 "conv: M=%d is not a multiple of %dx%d", p.M, p.out_H, p.out_W);
+    } else {
+        ME_CHECK(p.lda % 8 == 0 && p.lda >= p.K, ME_ERR_BAD_SHAPE, "gemm: lda=%lld K=%d",
+                 (long long)p.lda, p.K);
+    }
+    if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
+    const int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N);
+    if (dtype == ME_DTYPE_F16)
+        launch_typed<f16>(p, amode, epi, cfg, stream);
+    else if (dtype == ME_DTYPE_BF16)
+        launch_typed<bf16>(p, amode, epi, cfg, stream);
+    else
+        fail(ME_ERR_BAD_ARG, "gemm: bad dtype %d", dtype);
+}
+
+}  // namespace me

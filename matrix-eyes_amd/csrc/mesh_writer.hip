@@ -1,0 +1,250 @@
+// output.rs:195-261 output_mesh and its two writers (ObjWriter :484-630, PlyWriter :385-482).
+// Vertex ids, faces and coordinates come from the GPU kernels in output.hip; this file is the
+// host-side serialisation, byte-for-byte the reference's text/binary layout.
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "model.h"
+
+using namespace me;
+
+namespace {
+
+// Rust `{}` for f64: shortest digits that round-trip, positional notation, "1" for 1.0,
+// "-0" for -0.0, "NaN" / "inf" / "-inf".
+inline void put_f64(std::string& out, double v) {
+    if (std::isnan(v)) {
+        out += "NaN";
+        return;
+    }
+    if (std::isinf(v)) {
+        out += v < 0 ? "-inf" : "inf";
+        return;
+    }
+    char buf[400];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    out.append(buf, r.ptr);
+}
+
+inline void put_u64(std::string& out, unsigned long long v) {
+    char buf[24];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v);
+    out.append(buf, r.ptr);
+}
+
+struct FileSink {
+    FILE* f = nullptr;
+    std::string buf;
+    explicit FileSink(const std::string& path) {
+        f = fopen(path.c_str(), "wb");
+        ME_CHECK(f, ME_ERR_IO, "cannot create %s: %s", path.c_str(), strerror(errno));
+        buf.reserve(1 << 20);
+    }
+    ~FileSink() {
+        if (f) fclose(f);
+    }
+    void flush_if_full() {  // WRITE_BUFFER_SIZE, output.rs:383
+        if (buf.size() >= (1u << 20)) flush();
+    }
+    void flush() {
+        if (!buf.empty()) {
+            ME_CHECK(fwrite(buf.data(), 1, buf.size(), f) == buf.size(), ME_ERR_IO, "write failed: %s",
+                     strerror(errno));
+            buf.clear();
+        }
+    }
+    void close() {
+        flush();
+        const int r = fclose(f);
+        f = nullptr;
+        ME_CHECK(r == 0, ME_ERR_IO, "close failed: %s", strerror(errno));
+    }
+};
+
+bool ends_with_ci(const std::string& s, const char* suffix) {
+    const size_t n = strlen(suffix);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (tolower((unsigned char)s[s.size() - n + i]) != suffix[i]) return false;
+    return true;
+}
+
+// Path::file_stem / Path::parent for '/'-separated paths
+std::string file_stem(const std::string& path) {
+    const size_t slash = path.find_last_of('/');
+    std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot != 0) name = name.substr(0, dot);
+    return name;
+}
+std::string parent_dir(const std::string& path) {
+    const size_t slash = path.find_last_of('/');
+    if (slash == std::string::npos) return "";
+    return slash == 0 ? "/" : path.substr(0, slash);
+}
+
+void put_be64(std::string& out, double v) {
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    for (int i = 7; i >= 0; --i) out.push_back((char)((u >> (8 * i)) & 0xff));
+}
+void put_be32(std::string& out, uint32_t u) {
+    for (int i = 3; i >= 0; --i) out.push_back((char)((u >> (8 * i)) & 0xff));
+}
+
+}  // namespace
+
+extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
+                                  uint32_t original_width, uint32_t original_height,
+                                  const char* destination_path, const char* source_path,
+                                  int32_t vertex_mode, const uint8_t* vertex_colors) {
+    if (!ctx) return ME_ERR_BAD_ARG;
+    try {
+        ME_HIP(hipSetDevice(ctx->device));
+        ME_CHECK(depth && destination_path && source_path, ME_ERR_BAD_ARG,
+                 "me_output_mesh: null pointer");
+        ME_CHECK(vertex_mode >= ME_VERTEX_PLAIN && vertex_mode <= ME_VERTEX_TEXTURE, ME_ERR_BAD_ARG,
+                 "vertex mode %d", vertex_mode);
+        ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "me_output_mesh: %dx%d", width, height);
+        ME_CHECK(original_width > 0 && original_height > 0, ME_ERR_BAD_ARG, "original size 0");
+        const std::string dest(destination_path);
+        const bool ply = ends_with_ci(dest, ".ply"), obj = ends_with_ci(dest, ".obj");
+        ME_CHECK(ply || obj, ME_ERR_BAD_ARG, "mesh destination must end in .obj or .ply: %s",
+                 destination_path);
+        const bool with_color = vertex_mode == ME_VERTEX_COLOR && vertex_colors;
+
+        // ---- GPU: IndexedMesh::new + remap_face + vertex coordinates
+        const size_t nv = (size_t)width * height;
+        const size_t nt = 2 * (size_t)(width - 1) * (height - 1);
+        const float* d = (const float*)to_device(ctx, depth, nv * 4, "out.depth");
+        int32_t* vindex = (int32_t*)site_buf(ctx, "out.vindex", nv * 4);
+        int32_t* faces_dev = (int32_t*)site_buf(ctx, "out.faces", nt * 12);
+        int64_t nverts = 0, nfaces = 0;
+        mesh_index_run(d, width, height, vindex, faces_dev, &nverts, &nfaces, ctx->stream);
+        float* uv_dev = (float*)site_buf(ctx, "out.uv", nverts * 8 + 8);
+        float* xyz_dev = (float*)site_buf(ctx, "out.xyz", nverts * 12 + 12);
+        const uint32_t mx = original_width > original_height ? original_width : original_height;
+        mesh_vertices_launch(d, width, height, vindex, (float)original_width / (float)mx,
+                             (float)original_height / (float)mx, uv_dev, xyz_dev, ctx->stream);
+        std::vector<float> uv((size_t)nverts * 2), xyz((size_t)nverts * 3);
+        std::vector<int32_t> faces((size_t)nfaces * 3), vi;
+        if (nverts) {
+            ME_HIP(hipMemcpyAsync(uv.data(), uv_dev, uv.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            ME_HIP(hipMemcpyAsync(xyz.data(), xyz_dev, xyz.size() * 4, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        }
+        if (nfaces)
+            ME_HIP(hipMemcpyAsync(faces.data(), faces_dev, faces.size() * 4, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        std::vector<uint8_t> colors;  // per vertex id
+        if (with_color) {
+            vi.resize(nv);
+            ME_HIP(hipMemcpyAsync(vi.data(), vindex, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        ME_HIP(hipStreamSynchronize(ctx->stream));
+        if (with_color) {
+            std::vector<uint8_t> host_colors;
+            const uint8_t* src = vertex_colors;
+            if (is_device_ptr(vertex_colors)) {
+                host_colors.resize(nv * 3);
+                ME_HIP(hipMemcpy(host_colors.data(), vertex_colors, nv * 3, hipMemcpyDeviceToHost));
+                src = host_colors.data();
+            }
+            colors.resize((size_t)nverts * 3);
+            for (size_t i = 0; i < nv; ++i)
+                if (vi[i] >= 0) memcpy(&colors[(size_t)vi[i] * 3], src + i * 3, 3);
+        }
+
+        FileSink w(dest);
+        std::string& b = w.buf;
+        if (obj) {
+            const bool tex = vertex_mode == ME_VERTEX_TEXTURE;
+            const std::string stem = file_stem(dest);
+            if (tex) {  // output.rs:556-562
+                b += "mtllib " + stem + ".mtl\n";
+                b += "usemtl Textured\n";
+            }
+            if (tex)  // output.rs:592-602
+                for (int64_t i = 0; i < nverts; ++i) {
+                    w.flush_if_full();
+                    b += "vt ";
+                    put_f64(b, (double)uv[2 * i]);
+                    b += ' ';
+                    put_f64(b, 1.0 - (double)uv[2 * i + 1]);
+                    b += '\n';
+                }
+            for (int64_t i = 0; i < nverts; ++i) {  // output.rs:566-590
+                w.flush_if_full();
+                b += "v ";
+                put_f64(b, (double)xyz[3 * i]);
+                b += ' ';
+                put_f64(b, (double)(-xyz[3 * i + 1]));
+                b += ' ';
+                put_f64(b, (double)(-xyz[3 * i + 2]));
+                if (with_color)
+                    for (int c = 0; c < 3; ++c) {
+                        b += ' ';
+                        put_f64(b, (double)colors[3 * i + c] / 255.0);
+                    }
+                b += '\n';
+            }
+            for (int64_t f = 0; f < nfaces; ++f) {  // output.rs:604-620
+                w.flush_if_full();
+                b += 'f';
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned long long idx = (unsigned long long)faces[3 * f + k] + 1;
+                    b += ' ';
+                    put_u64(b, idx);
+                    if (tex) {
+                        b += '/';
+                        put_u64(b, idx);
+                    }
+                }
+                b += '\n';
+            }
+            w.close();
+            if (tex) {  // output.rs:525-547 write_materials
+                const std::string dir = parent_dir(dest);
+                FileSink m((dir.empty() ? std::string() : dir + "/") + stem + ".mtl");
+                m.buf += "newmtl Textured\nKa 0.2 0.2 0.2\nKd 0.8 0.8 0.8\nKs 1.0 1.0 1.0\nillum 2\n";
+                m.buf += "Ns 0.000500\n";
+                m.buf += std::string("map_Ka ") + source_path + "\n";
+                m.buf += std::string("map_Kd ") + source_path + "\n\n";
+                m.close();
+            }
+        } else {
+            // output.rs:415-438
+            b += "ply\nformat binary_big_endian 1.0\ncomment Matrix Eyes 3D surface\n";
+            b += "element vertex " + std::to_string(nverts) + "\n";
+            b += "property double x\nproperty double y\nproperty double z\n";
+            if (vertex_mode == ME_VERTEX_COLOR)
+                b += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
+            b += "element face " + std::to_string(nfaces) + "\n";
+            b += "property list uchar int vertex_indices\nend_header\n";
+            for (int64_t i = 0; i < nverts; ++i) {  // output.rs:440-458
+                w.flush_if_full();
+                put_be64(b, (double)xyz[3 * i]);
+                put_be64(b, (double)(-xyz[3 * i + 1]));
+                put_be64(b, (double)(-xyz[3 * i + 2]));
+                if (with_color) b.append((const char*)&colors[3 * i], 3);
+            }
+            for (int64_t f = 0; f < nfaces; ++f) {  // output.rs:464-473
+                w.flush_if_full();
+                b.push_back((char)3);
+                for (int k = 0; k < 3; ++k) put_be32(b, (uint32_t)faces[3 * f + k]);
+            }
+            w.close();
+        }
+    } catch (const me::Error& e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        ctx->last_error = std::string("internal: ") + e.what();
+        return ME_ERR_IO;
+    }
+    return ME_OK;
+}

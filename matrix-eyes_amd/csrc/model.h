@@ -1,0 +1,148 @@
+// Context, packed weights and stage functions of the Depth Pro forward pass.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace me {
+
+// How a checkpoint tensor (PyTorch layout) is packed into the device arena.
+enum PackKind : int32_t {
+    PK_VEC_F32 = 0,  // any shape -> flat f32 (biases, LayerNorm, LayerScale, cls/pos)
+    PK_MAT_16 = 1,   // [N][K...] row-major -> 16-bit [N][K]  (Linear, 1x1 conv, patch embed)
+    PK_CONV_16 = 2,  // Conv2d [Cout][Cin][kh][kw] -> 16-bit [Cout][kh*kw][Cin]
+    PK_CONVT_16 = 3, // ConvTranspose2d [Cin][Cout][2][2] -> 16-bit [(dy*2+dx)*Cout + co][Cin]
+    PK_CONVK_F32 = 4 // Conv2d [1][Cin][k][k] -> f32 [k][k][Cin]  (fov.head.4)
+};
+
+struct WeightSlot {
+    std::string name;
+    std::vector<int64_t> dims;
+    PackKind kind;
+    size_t offset = 0, bytes = 0;
+    bool loaded = false;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+};
+
+struct VitBlockW {
+    const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ls1, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls2;
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct VitW {
+    const void* patch_w;
+    const float *patch_b, *cls, *pos, *norm_w, *norm_b;
+    std::vector<VitBlockW> blocks;
+};
+struct UpsampleW {
+    const void* conv;               // 1x1 [dim_int][C]
+    std::vector<const void*> convt; // packed [4*Cout][Cin]
+    std::vector<int> cin, cout;
+    int dim_int;
+};
+struct RcuW {
+    const void* w[2];
+    const float* b[2];
+};
+struct FusionW {
+    RcuW resnet1, resnet2;
+    const void* deconv;  // null at level 0
+    const void* out_w;
+    const float* out_b;
+};
+struct ModelW {
+    VitW vit[3];
+    UpsampleW up_latent0, up_latent1, up0, up1, up2;
+    const void* up_lowres_w;
+    const float* up_lowres_b;
+    const void* fuse_w;
+    const float* fuse_b;
+    const void* dec_convs[5];  // [i] for level i (null for level 0)
+    FusionW fusions[5];
+    const void *head0_w, *head1_w, *head2_w;
+    const float *head0_b, *head1_b, *head2_b, *head4_w, *head4_b;
+    const void *fov_lin_w, *fov_down_w, *fov_h0_w, *fov_h2_w;
+    const float *fov_lin_b, *fov_down_b, *fov_h0_b, *fov_h2_b, *fov_h4_w, *fov_h4_b;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace me
+
+// The opaque C handle.
+struct me_ctx {
+    int device = 0;
+    int32_t dtype = ME_DTYPE_F16;
+    me_model_config cfg;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;  // image/FOV encoders run beside the patch encoder
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::string last_error;
+    me_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
+
+    // weights
+    std::vector<me::WeightSlot> slots;
+    std::map<std::string, int> slot_by_name;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool finalized = false;
+    me::ModelW w;
+
+    // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
+    std::map<std::string, me::DevBuf> bufs;
+
+    // geometry helpers
+    int g() const { return cfg.grid; }
+    int P() const { return cfg.grid * cfg.grid; }
+    int T() const { return cfg.grid * cfg.grid + 1; }
+    int S() const { return 64 * cfg.grid; }
+    int C() const { return cfg.embed_dim; }
+};
+
+namespace me {
+
+void build_weight_table(me_ctx* ctx);
+void resolve_weights(me_ctx* ctx);
+void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight_dtype,
+                 const int64_t* dims, int32_t ndim);
+void finalize_weights(me_ctx* ctx);
+
+// persistent device buffer for a pipeline site; zero-filled when (re)allocated
+void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes);
+
+// host-or-device pointer helpers
+bool is_device_ptr(const void* p);
+// returns a device pointer holding `bytes` of `p` (copying through site buffer `name` if host)
+const void* to_device(me_ctx* ctx, const void* p, size_t bytes, const std::string& name);
+// device result -> caller pointer (host or device)
+void from_device(me_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+
+// ---- stages (all device pointers; see pipeline.hip) ----
+struct VitTaps {
+    // called after block `index` with the f32 token stream [W*T][C]
+    void (*fn)(void* user, int index, const float* tokens) = nullptr;
+    void* user = nullptr;
+};
+// patches16 [W*P][768] -> tokens32 (residual stream, scratch) ; final LayerNorm written to
+// final16 (16-bit) and/or final32.  `tag` names the scratch buffers (one set per stream).
+void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
+                 void* final16, float* final32, const std::string& tag, hipStream_t stream);
+
+void stage_encoder(me_ctx* ctx, const float* img32, int B);
+void stage_decoder(me_ctx* ctx, int B, bool want_features32);
+void stage_fov(me_ctx* ctx, int B, float* fov_deg_dev);
+// f_norm_dev [B]; clamp 0 = canonical (no clamp, f_norm ignored -> 1)
+void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
+
+void report(me_ctx* ctx, float pos, const char* msg);
+
+}  // namespace me

@@ -1,0 +1,438 @@
+// The Depth Pro forward pass as a sequence of HIP kernel launches on one stream.
+// Stage structure follows reference src/depth_pro/mod.rs:251-363; each function cites the
+// module forward() it replaces.  Activations live in HBM as:
+//   - ViT: f32 residual stream [windows*tokens][C] + 16-bit GEMM operands
+//   - conv stages: NHWC; 16-bit operands of 3x3 convs carry a 1-pixel zero border
+//     ([B][H+2][W+2][C]) so the implicit-GEMM loader needs no bounds checks, residual paths
+//     stay f32 ([B*H*W][C]).
+#include "model.h"
+
+namespace me {
+
+void report(me_ctx* ctx, float pos, const char* msg) {
+    if (ctx->progress) ctx->progress(ctx->progress_user, pos, msg);
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory is "invalid value": not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes) {
+    DevBuf& b = ctx->bufs[name];
+    if (b.p && b.bytes >= bytes) return b.p;
+    if (b.p) {
+        ME_HIP(hipStreamSynchronize(ctx->stream));
+        ME_HIP(hipFree(b.p));
+        b.p = nullptr, b.bytes = 0;
+    }
+    ME_HIP(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    ME_HIP(hipMemsetAsync(b.p, 0, bytes, ctx->stream));
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    return b.p;
+}
+
+const void* to_device(me_ctx* ctx, const void* p, size_t bytes, const std::string& name) {
+    if (is_device_ptr(p)) return p;
+    void* d = site_buf(ctx, name, bytes);
+    ME_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return d;
+}
+
+void from_device(me_ctx* ctx, void* dst, const void* src_dev, size_t bytes) {
+    if (is_device_ptr(dst)) {
+        if (dst != src_dev)
+            ME_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        ME_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ME_HIP(hipStreamSynchronize(ctx->stream));
+    }
+}
+
+namespace {
+
+// ---- thin launch helpers ---------------------------------------------------------------
+GemmParams base_params() {
+    GemmParams p = GemmParams();  // value-initialised: every pointer null, every int 0
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    return p;
+}
+
+// out = act(A[M][K] . W[N][K]^T + bias) as 16-bit and/or f32 rows of stride ldc
+void linear(me_ctx* ctx, const void* A, int64_t M, int K, const void* W, int N, const float* bias,
+            void* out16, float* out32, int64_t ldc, int act, hipStream_t s) {
+    GemmParams p = base_params();
+    p.M = (int)M, p.N = N, p.K = K, p.A = A, p.lda = K, p.W = W, p.bias = bias;
+    p.out16 = out16, p.out32 = out32, p.ldc = ldc, p.act = act;
+    gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
+}
+
+struct ConvOut {
+    float* out32 = nullptr;   // [B*H*W][Cout]
+    void* out16 = nullptr;    // 16-bit copy
+    bool border16 = false;    // out16 is [B][H+2][W+2][Cout]
+    int act = ACT_NONE;       // applied to out16 (and out32 unless act16_only)
+    bool act16_only = true;
+    const float* res32 = nullptr;
+    const float* res32b = nullptr;
+};
+
+// Conv2d k x k (k = 1 or 3, pad (k-1)/2, stride 1 or 2) on a zero-bordered NHWC operand
+void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, const void* W, int Cout,
+          int k, int stride, const float* bias, const ConvOut& o, hipStream_t s) {
+    GemmParams p = base_params();
+    const int Ho = Hin / stride, Wo = Win / stride;
+    p.M = B * Ho * Wo, p.N = Cout, p.K = k * k * Cin;
+    p.A = in16b, p.in_Hp = Hin + 2, p.in_Wp = Win + 2, p.Cin = Cin;
+    p.out_H = Ho, p.out_W = Wo, p.KH = k, p.KW = k, p.stride = stride;
+    p.W = W, p.bias = bias, p.res32 = o.res32, p.res32b = o.res32b;
+    p.out32 = o.out32, p.out16 = o.out16, p.ldc = Cout, p.out16_border = o.border16 ? 1 : 0;
+    p.act = o.act, p.act16_only = o.act16_only ? 1 : 0;
+    gemm_launch(p, A_CONV, EPI_STORE, ctx->dtype, s);
+}
+
+// ConvTranspose2d(2,2,stride 2) of an unbordered NHWC operand [B*H*W][Cin] -> [B][2H][2W][Cout]
+void convt(me_ctx* ctx, const void* in16, int B, int H, int W_, int Cin, const void* W, int Cout,
+           const float* bias, float* out32, void* out16, bool border16, int64_t pixel_stride,
+           int act16, hipStream_t s) {
+    GemmParams p = base_params();
+    p.M = B * H * W_, p.N = 4 * Cout, p.K = Cin, p.A = in16, p.lda = Cin, p.W = W, p.bias = bias;
+    p.out_H = H, p.out_W = W_, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
+    p.out16_border = border16 ? 1 : 0, p.ldc = pixel_stride ? pixel_stride : Cout, p.act = act16;
+    gemm_launch(p, A_PLAIN, EPI_CONVT, ctx->dtype, s);
+}
+
+size_t bordered_bytes(int B, int H, int W, int C) { return (size_t)B * (H + 2) * (W + 2) * C * 2; }
+
+// encoder.rs:210-216 forward_seq over an upsample block: 1x1 conv (no bias) then ConvT x n.
+// The last ConvT writes the caller's outputs.
+void run_upsample(me_ctx* ctx, const std::string& tag, const void* in16, int B, int H,
+                  const UpsampleW& u, float* last32, void* last16, bool last_border,
+                  int64_t last_pixel_stride, int last_act16, hipStream_t s) {
+    const int C = ctx->C();
+    const int64_t M = (int64_t)B * H * H;
+    void* a = site_buf(ctx, tag + ".proj", (size_t)M * u.dim_int * 2);
+    linear(ctx, in16, M, C, u.conv, u.dim_int, nullptr, a, nullptr, u.dim_int, ACT_NONE, s);
+    const void* cur = a;
+    int h = H;
+    const int n = (int)u.convt.size();
+    for (int i = 0; i < n; ++i) {
+        const bool last = i == n - 1;
+        if (last) {
+            convt(ctx, cur, B, h, h, u.cin[i], u.convt[i], u.cout[i], nullptr, last32, last16,
+                  last_border, last_pixel_stride, last_act16, s);
+        } else {
+            void* t = site_buf(ctx, tag + ".up" + std::to_string(i),
+                               (size_t)B * 4 * h * h * u.cout[i] * 2);
+            convt(ctx, cur, B, h, h, u.cin[i], u.convt[i], u.cout[i], nullptr, nullptr, t, false, 0,
+                  ACT_NONE, s);
+            cur = t;
+        }
+        h *= 2;
+    }
+}
+
+struct TapCtx {
+    me_ctx* ctx;
+    int B;
+    void *lat0, *lat1;
+    hipStream_t s;
+};
+
+void tap_fn(void* user, int index, const float* tokens) {
+    TapCtx* t = (TapCtx*)user;
+    me_ctx* ctx = t->ctx;
+    // encoder.rs:266-280: reshape_feature + merge of the first 25 windows, padding 3 (= g/8)
+    void* dst = index == ctx->cfg.tap_blocks[0] ? t->lat0
+                                                : (index == ctx->cfg.tap_blocks[1] ? t->lat1 : nullptr);
+    if (dst)
+        merge_launch(tokens, nullptr, dst, t->B, 35, 0, 5, ctx->g() / 8, ctx->g(), ctx->C(),
+                     ctx->dtype, t->s);
+}
+
+}  // namespace
+
+// vit.rs:287-346: prepare_tokens_with_mask, 24 x Block::forward, final LayerNorm
+void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
+                 void* final16, float* final32, const std::string& tag, hipStream_t s) {
+    const VitW& v = ctx->w.vit[which];
+    const int C = ctx->C(), T = ctx->T(), P = ctx->P(), heads = ctx->cfg.num_heads;
+    const int64_t rows = (int64_t)W * T;
+    float* tok = (float*)site_buf(ctx, tag + ".tokens", (size_t)rows * C * 4);
+    void* xn = site_buf(ctx, tag + ".xn", (size_t)rows * C * 2);
+    void* qkv = site_buf(ctx, tag + ".qkv", (size_t)rows * 3 * C * 2);
+    void* att = site_buf(ctx, tag + ".att", (size_t)rows * C * 2);
+    void* hid = site_buf(ctx, tag + ".hid", (size_t)rows * 4 * C * 2);
+
+    // vit.rs:287-295: patch embed + cls + pos
+    cls_rows_launch(tok, v.cls, v.pos, W, T, C, s);
+    {
+        GemmParams p = base_params();
+        p.M = W * P, p.N = C, p.K = 768, p.A = patches16, p.lda = 768, p.W = v.patch_w;
+        p.bias = v.patch_b, p.pos = v.pos, p.out32 = tok, p.ldc = C, p.tokens_per_window = P;
+        gemm_launch(p, A_PLAIN, EPI_PATCH_EMBED, ctx->dtype, s);
+    }
+    for (int i = 0; i < ctx->cfg.depth; ++i) {
+        const VitBlockW& b = v.blocks[i];
+        // vit.rs:163-170 Block::forward
+        layernorm_launch(tok, b.ln1_w, b.ln1_b, xn, nullptr, rows, C, ctx->cfg.ln_eps, ctx->dtype, s);
+        linear(ctx, xn, rows, C, b.qkv_w, 3 * C, b.qkv_b, qkv, nullptr, 3 * C, ACT_NONE, s);
+        attention_launch(qkv, att, W, T, heads, ctx->dtype, s);
+        {
+            GemmParams p = base_params();
+            p.M = (int)rows, p.N = C, p.K = C, p.A = att, p.lda = C, p.W = b.proj_w;
+            p.bias = b.proj_b, p.gamma = b.ls1, p.res32 = tok, p.out32 = tok, p.ldc = C;
+            gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s);
+        }
+        layernorm_launch(tok, b.ln2_w, b.ln2_b, xn, nullptr, rows, C, ctx->cfg.ln_eps, ctx->dtype, s);
+        linear(ctx, xn, rows, C, b.fc1_w, 4 * C, b.fc1_b, hid, nullptr, 4 * C, ACT_GELU, s);
+        {
+            GemmParams p = base_params();
+            p.M = (int)rows, p.N = C, p.K = 4 * C, p.A = hid, p.lda = 4 * C, p.W = b.fc2_w;
+            p.bias = b.fc2_b, p.gamma = b.ls2, p.res32 = tok, p.out32 = tok, p.ldc = C;
+            gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s);
+        }
+        if (taps.fn) taps.fn(taps.user, i, tok);
+    }
+    // vit.rs:343 final norm
+    layernorm_launch(tok, v.norm_w, v.norm_b, final16, final32, rows, C, ctx->cfg.ln_eps, ctx->dtype,
+                     s);
+}
+
+// encoder.rs:218-335 DepthProEncoder::forward_encodings
+void stage_encoder(me_ctx* ctx, const float* img32, int B) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), S = ctx->S(), C = ctx->C(), P = ctx->P(), T = ctx->T();
+    const int dec = c.dec_dim, e0 = c.enc_dims[0], e1 = c.enc_dims[1], e2 = c.enc_dims[2],
+              e3 = c.enc_dims[3];
+    report(ctx, 0.0f, "creating image pyramid");
+    // encoder.rs:125-140 create_pyramid (x0 itself only changes type)
+    void* x0 = site_buf(ctx, "enc.x0", (size_t)B * 3 * S * S * 2);
+    void* x1 = site_buf(ctx, "enc.x1", (size_t)B * 3 * (S / 2) * (S / 2) * 2);
+    void* x2 = site_buf(ctx, "enc.x2", (size_t)B * 3 * (S / 4) * (S / 4) * 2);
+    cast_f32_to_16_launch(img32, x0, (int64_t)B * 3 * S * S, ctx->dtype, s);
+    bilinear_launch(img32, x1, 3 * B, S, S / 2, c.align_corners, ctx->dtype, s);
+    bilinear_launch(img32, x2, 3 * B, S, S / 4, c.align_corners, ctx->dtype, s);
+    // encoder.rs:238-250 split + cat, vit.rs:210-223 patch embed im2col
+    report(ctx, 0.02f, "preparing image patches");
+    void* patches = site_buf(ctx, "enc.patches", (size_t)B * 35 * P * 768 * 2);
+    patchify_launch(x0, x1, x2, patches, B, g, ctx->dtype, s);
+
+    report(ctx, 0.03f, "encoding patches");
+    const int side0 = 4 * g, side1 = 2 * g;
+    void* lat0 = site_buf(ctx, "enc.lat0", (size_t)B * side0 * side0 * C * 2);
+    void* lat1 = site_buf(ctx, "enc.lat1", (size_t)B * side0 * side0 * C * 2);
+    void* tok16 = site_buf(ctx, "enc.tok16", (size_t)B * 35 * T * C * 2);
+    TapCtx tc{ctx, B, lat0, lat1, s};
+    VitTaps taps;
+    taps.fn = tap_fn, taps.user = &tc;
+    vit_forward(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, tok16, nullptr, "vit.patch", s);
+
+    report(ctx, 0.55f, "reshaping patch encodings");
+    // encoder.rs:263,285-294: split_with_sizes + merge
+    void* x0f = site_buf(ctx, "enc.x0f", (size_t)B * side0 * side0 * C * 2);
+    void* x1f = site_buf(ctx, "enc.x1f", (size_t)B * side1 * side1 * C * 2);
+    void* x2f = site_buf(ctx, "enc.x2f", (size_t)B * g * g * C * 2);
+    merge_launch(nullptr, tok16, x0f, B, 35, 0, 5, g / 8, g, C, ctx->dtype, s);
+    merge_launch(nullptr, tok16, x1f, B, 35, 25, 3, g / 4, g, C, ctx->dtype, s);
+    merge_launch(nullptr, tok16, x2f, B, 35, 34, 1, 0, g, C, ctx->dtype, s);
+
+    report(ctx, 0.6f, "encoding image");
+    // encoder.rs:298-303 image encoder on the 1/4 image
+    void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
+    patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s);
+    void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
+    vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s);
+    void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2);
+    merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s);
+
+    report(ctx, 0.7f, "encoding features");
+    // encoder.rs:307-316
+    const int H0 = 32 * g, H1 = 16 * g, H2 = 8 * g, H3 = 4 * g, H4 = 2 * g;
+    float* enc0_32 = (float*)site_buf(ctx, "enc0.f32", (size_t)B * H0 * H0 * dec * 4);
+    void* enc0_r16 = site_buf(ctx, "enc0.r16b", bordered_bytes(B, H0, H0, dec));
+    run_upsample(ctx, "up_latent0", lat0, B, side0, ctx->w.up_latent0, enc0_32, enc0_r16, true, 0,
+                 ACT_RELU, s);
+    void* enc1 = site_buf(ctx, "enc1.16b", bordered_bytes(B, H1, H1, e0));
+    run_upsample(ctx, "up_latent1", lat1, B, side0, ctx->w.up_latent1, nullptr, enc1, true, 0,
+                 ACT_NONE, s);
+    void* enc2 = site_buf(ctx, "enc2.16b", bordered_bytes(B, H2, H2, e1));
+    run_upsample(ctx, "up0", x0f, B, side0, ctx->w.up0, nullptr, enc2, true, 0, ACT_NONE, s);
+    void* enc3 = site_buf(ctx, "enc3.16b", bordered_bytes(B, H3, H3, e2));
+    run_upsample(ctx, "up1", x1f, B, side1, ctx->w.up1, nullptr, enc3, true, 0, ACT_NONE, s);
+    // encoder.rs:316-325: upsample2, upsample_lowres, cat on channels, fuse_lowres
+    char* cat = (char*)site_buf(ctx, "enc.cat", (size_t)B * H4 * H4 * 2 * e3 * 2);
+    run_upsample(ctx, "up2", x2f, B, g, ctx->w.up2, nullptr, cat, false, 2 * e3, ACT_NONE, s);
+    report(ctx, 0.9f, "upsampling lowres");
+    convt(ctx, xg, B, g, g, C, ctx->w.up_lowres_w, e3, ctx->w.up_lowres_b, nullptr, cat + (size_t)e3 * 2,
+          false, 2 * e3, ACT_NONE, s);
+    report(ctx, 0.95f, "fusing lowres");
+    void* enc4 = site_buf(ctx, "enc4.16b", bordered_bytes(B, H4, H4, e3));
+    {
+        GemmParams p = base_params();
+        p.M = B * H4 * H4, p.N = e3, p.K = 2 * e3, p.A = cat, p.lda = 2 * e3, p.W = ctx->w.fuse_w;
+        p.bias = ctx->w.fuse_b, p.out16 = enc4, p.out16_border = 1, p.ldc = e3;
+        p.out_H = H4, p.out_W = H4;
+        gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
+    }
+}
+
+// decoder.rs:153-208 MultiresConvDecoder::forward (+ :84-102 FeatureFusionBlock, :35-44 RCU)
+void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), dec = c.dec_dim;
+    const int H[5] = {32 * g, 16 * g, 8 * g, 4 * g, 2 * g};
+    const int Cin[5] = {dec, c.enc_dims[0], c.enc_dims[1], c.enc_dims[2], c.enc_dims[3]};
+    const char* enc_names[5] = {"enc0.r16b", "enc1.16b", "enc2.16b", "enc3.16b", "enc4.16b"};
+
+    float* feat32 = nullptr;  // `features` carried between levels (f32 residual path)
+    for (int i = 4; i >= 0; --i) {
+        report(ctx, (4 - i) / 5.0f, i == 4 ? "decoding initial block" : "decoding blocks");
+        const std::string L = "dec" + std::to_string(i);
+        const int h = H[i];
+        const size_t n32 = (size_t)B * h * h * dec * 4, nb = bordered_bytes(B, h, h, dec);
+        const FusionW& fw = ctx->w.fusions[i];
+        const void* enc = ctx->bufs.at(enc_names[i]).p;
+
+        // features_i = convs[i-1](encoding) (3x3, no bias); level 0 uses the encoding as is
+        float* x1_32;
+        void* x1_r16;
+        if (i == 0) {
+            x1_32 = (float*)ctx->bufs.at("enc0.f32").p;
+            x1_r16 = (void*)enc;
+        } else {
+            // level 4's conv output is `lowres_features` (decoder.rs:178), kept for the FOV head
+            x1_32 = (float*)site_buf(ctx, i == 4 ? std::string("lowres.f32") : L + ".x1.f32", n32);
+            x1_r16 = site_buf(ctx, L + ".x1.r16b", nb);
+            ConvOut o;
+            o.out32 = x1_32, o.out16 = x1_r16, o.border16 = true, o.act = ACT_RELU;
+            conv(ctx, enc, B, h, h, Cin[i], ctx->w.dec_convs[i], dec, 3, 1, nullptr, o, s);
+        }
+
+        float* out32;
+        void* out_r16;
+        if (i == 4) {
+            // decoder.rs:171-183: lowres_features = features.clone(); fusions.last()(features, None)
+            out32 = x1_32;
+            out_r16 = x1_r16;
+        } else {
+            // out = x0 + resnet1(x1) = x0 + x1 + conv2(relu(conv1(relu(x1))))
+            void* t_r16 = site_buf(ctx, L + ".t1.r16b", nb);
+            ConvOut o1;
+            o1.out16 = t_r16, o1.border16 = true, o1.act = ACT_RELU;
+            conv(ctx, x1_r16, B, h, h, dec, fw.resnet1.w[0], dec, 3, 1, fw.resnet1.b[0], o1, s);
+            out32 = (float*)site_buf(ctx, L + ".out.f32", n32);
+            out_r16 = site_buf(ctx, L + ".out.r16b", nb);
+            ConvOut o2;
+            o2.out32 = out32, o2.out16 = out_r16, o2.border16 = true, o2.act = ACT_RELU;
+            o2.res32 = x1_32, o2.res32b = feat32;
+            conv(ctx, t_r16, B, h, h, dec, fw.resnet1.w[1], dec, 3, 1, fw.resnet1.b[1], o2, s);
+        }
+        // resnet2
+        void* t2_r16 = site_buf(ctx, L + ".t2.r16b", nb);
+        ConvOut o3;
+        o3.out16 = t2_r16, o3.border16 = true, o3.act = ACT_RELU;
+        conv(ctx, out_r16, B, h, h, dec, fw.resnet2.w[0], dec, 3, 1, fw.resnet2.b[0], o3, s);
+        void* v16 = site_buf(ctx, L + ".v16", (size_t)B * h * h * dec * 2);
+        ConvOut o4;
+        o4.out16 = v16, o4.res32 = out32;
+        conv(ctx, t2_r16, B, h, h, dec, fw.resnet2.w[1], dec, 3, 1, fw.resnet2.b[1], o4, s);
+        // deconv (levels 1-4) then out_conv 1x1 (+bias)
+        const void* pre = v16;
+        int ho = h;
+        if (fw.deconv) {
+            void* d16 = site_buf(ctx, L + ".d16", (size_t)B * 4 * h * h * dec * 2);
+            convt(ctx, v16, B, h, h, dec, fw.deconv, dec, nullptr, nullptr, d16, false, 0, ACT_NONE, s);
+            pre = d16, ho = 2 * h;
+        }
+        const int64_t Mo = (int64_t)B * ho * ho;
+        if (i > 0) {
+            feat32 = (float*)site_buf(ctx, L + ".feat.f32", (size_t)Mo * dec * 4);
+            linear(ctx, pre, Mo, dec, fw.out_w, dec, fw.out_b, nullptr, feat32, dec, ACT_NONE, s);
+        } else {
+            // final features: 16-bit zero-bordered operand of head[0]; f32 copy for the ABI
+            float* f32 = want_features32 ? (float*)site_buf(ctx, "features.f32", (size_t)Mo * dec * 4)
+                                         : nullptr;
+            void* f16b = site_buf(ctx, "features.16b", bordered_bytes(B, ho, ho, dec));
+            GemmParams p = base_params();
+            p.M = (int)Mo, p.N = dec, p.K = dec, p.A = pre, p.lda = dec, p.W = fw.out_w;
+            p.bias = fw.out_b, p.out16 = f16b, p.out16_border = 1, p.out32 = f32, p.ldc = dec;
+            p.out_H = ho, p.out_W = ho;
+            gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
+        }
+    }
+}
+
+// mod.rs:323-333 head convs + ReLUs, mod.rs:361-362 div_scalar + clamp fused into the last kernel
+void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int dec = c.dec_dim, S = ctx->S(), Hh = S / 2;
+    report(ctx, 0.0f, "forwarding head");
+    const void* f16b = ctx->bufs.at("features.16b").p;
+    void* h0 = site_buf(ctx, "head.h0", (size_t)B * Hh * Hh * (dec / 2) * 2);
+    ConvOut o;
+    o.out16 = h0;
+    conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s);
+    void* h1 = site_buf(ctx, "head.h1b", bordered_bytes(B, S, S, dec / 2));
+    convt(ctx, h0, B, Hh, Hh, dec / 2, ctx->w.head1_w, dec / 2, ctx->w.head1_b, nullptr, h1, true, 0,
+          ACT_NONE, s);
+    GemmParams p = base_params();
+    p.M = B * S * S, p.N = c.head_dims[0], p.K = 9 * (dec / 2);
+    p.A = h1, p.in_Hp = S + 2, p.in_Wp = S + 2, p.Cin = dec / 2, p.out_H = S, p.out_W = S;
+    p.KH = 3, p.KW = 3, p.stride = 1, p.W = ctx->w.head2_w, p.bias = ctx->w.head2_b;
+    p.w2 = ctx->w.head4_w, p.b2 = ctx->w.head4_b, p.f_norm = f_norm_dev;
+    p.pixels_per_image = S * S, p.out32 = depth_dev;
+    if (clamp) p.clamp_lo = 1e-4f, p.clamp_hi = 1e4f;
+    gemm_launch(p, A_CONV, EPI_HEAD_FINAL, ctx->dtype, s);
+}
+
+// fov.rs:40-88 FOVNetwork::forward; needs "enc.x2" (the 1/4 image) and "lowres.f32"
+void stage_fov(me_ctx* ctx, int B, float* fov_deg_dev) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), C = ctx->C(), P = ctx->P(), T = ctx->T(), dec = c.dec_dim;
+    report(ctx, 0.0f, "encoding fov");
+    const void* x2 = ctx->bufs.at("enc.x2").p;
+    void* patches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
+    patchify_windows_launch(x2, patches, B, g, ctx->dtype, s);
+    void* tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
+    vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
+    report(ctx, 0.8f, "fov linear");
+    float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
+    linear(ctx, tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
+           dec / 2, ACT_NONE, s);
+    report(ctx, 0.85f, "fov lowres");
+    // fov.rs:70-74: relu(downsample[0](lowres)) + reshaped tokens
+    const float* low32 = (const float*)ctx->bufs.at("lowres.f32").p;
+    void* low16b = site_buf(ctx, "fov.low16b", bordered_bytes(B, 2 * g, 2 * g, dec));
+    nhwc32_to_16b_launch(low32, low16b, B, 2 * g, 2 * g, dec, 0, ctx->dtype, s);
+    float* fl32 = (float*)site_buf(ctx, "fov.down", (size_t)B * P * (dec / 2) * 4);
+    ConvOut o0;
+    o0.out32 = fl32, o0.act = ACT_RELU, o0.act16_only = false;
+    conv(ctx, low16b, B, 2 * g, 2 * g, dec, ctx->w.fov_down_w, dec / 2, 3, 2, ctx->w.fov_down_b, o0, s);
+    void* fx = site_buf(ctx, "fov.x16b", bordered_bytes(B, g, g, dec / 2));
+    fov_add_relu_launch(lin32, fl32, fx, B, g, dec / 2, T, ctx->dtype, s);
+    // fov.rs:77-85 head
+    void* f1 = site_buf(ctx, "fov.h0b", bordered_bytes(B, g / 2, g / 2, dec / 4));
+    ConvOut o1;
+    o1.out16 = f1, o1.border16 = true, o1.act = ACT_RELU;
+    conv(ctx, fx, B, g, g, dec / 2, ctx->w.fov_h0_w, dec / 4, 3, 2, ctx->w.fov_h0_b, o1, s);
+    void* f2 = site_buf(ctx, "fov.h2", (size_t)B * (g / 4) * (g / 4) * (dec / 8) * 2);
+    ConvOut o2;
+    o2.out16 = f2, o2.act = ACT_RELU;
+    conv(ctx, f1, B, g / 2, g / 2, dec / 4, ctx->w.fov_h2_w, dec / 8, 3, 2, ctx->w.fov_h2_b, o2, s);
+    float* fnorm = (float*)site_buf(ctx, "f_norm", (size_t)B * 4);
+    fov_final_launch(f2, ctx->w.fov_h4_w, ctx->w.fov_h4_b, fov_deg_dev, fnorm, B, g / 4, dec / 8,
+                     ctx->dtype, s);
+}
+
+}  // namespace me

@@ -1,0 +1,355 @@
+// Checkpoint ingestion: the table of tensors the model expects (PyTorch names and layouts,
+// SURVEY App. C / reference mod.rs:185-210 remap rules), packing into one device arena in the
+// layouts the kernels read, and the typed views (ModelW) over that arena.
+//
+// The reference builds each stage's modules, loads and drops them per call (mod.rs:276-351);
+// here all 952 M parameters stay resident (1.9 GB of 288 GB) in ONE allocation so that a
+// multi-GPU job moves them with a single RCCL broadcast (rccl_bcast.hip).
+#include <cstring>
+
+#include "model.h"
+
+namespace me {
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void add_slot(me_ctx* ctx, const std::string& name, std::vector<int64_t> dims, PackKind kind) {
+    WeightSlot s;
+    s.name = name;
+    s.dims = std::move(dims);
+    s.kind = kind;
+    const bool f32 = kind == PK_VEC_F32 || kind == PK_CONVK_F32;
+    s.bytes = (size_t)s.numel() * (f32 ? 4 : 2);
+    s.offset = ctx->arena_bytes;
+    ctx->arena_bytes = align_up(ctx->arena_bytes + s.bytes, 256);
+    ctx->slot_by_name[name] = (int)ctx->slots.size();
+    ctx->slots.push_back(std::move(s));
+}
+
+void add_vit(me_ctx* ctx, const std::string& p) {
+    const int64_t C = ctx->C(), T = ctx->T();
+    add_slot(ctx, p + "cls_token", {1, 1, C}, PK_VEC_F32);
+    add_slot(ctx, p + "pos_embed", {1, T, C}, PK_VEC_F32);
+    add_slot(ctx, p + "patch_embed.proj.weight", {C, 3, 16, 16}, PK_MAT_16);
+    add_slot(ctx, p + "patch_embed.proj.bias", {C}, PK_VEC_F32);
+    for (int i = 0; i < ctx->cfg.depth; ++i) {
+        const std::string b = p + "blocks." + std::to_string(i) + ".";
+        add_slot(ctx, b + "norm1.weight", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "norm1.bias", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "attn.qkv.weight", {3 * C, C}, PK_MAT_16);
+        add_slot(ctx, b + "attn.qkv.bias", {3 * C}, PK_VEC_F32);
+        add_slot(ctx, b + "attn.proj.weight", {C, C}, PK_MAT_16);
+        add_slot(ctx, b + "attn.proj.bias", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "ls1.gamma", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "norm2.weight", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "norm2.bias", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "mlp.fc1.weight", {4 * C, C}, PK_MAT_16);
+        add_slot(ctx, b + "mlp.fc1.bias", {4 * C}, PK_VEC_F32);
+        add_slot(ctx, b + "mlp.fc2.weight", {C, 4 * C}, PK_MAT_16);
+        add_slot(ctx, b + "mlp.fc2.bias", {C}, PK_VEC_F32);
+        add_slot(ctx, b + "ls2.gamma", {C}, PK_VEC_F32);
+    }
+    add_slot(ctx, p + "norm.weight", {C}, PK_VEC_F32);
+    add_slot(ctx, p + "norm.bias", {C}, PK_VEC_F32);
+}
+
+// encoder.rs:85-118 init_project_upsample_block
+void add_upsample(me_ctx* ctx, const std::string& p, int64_t dim_out, int layers, int64_t dim_int) {
+    add_slot(ctx, p + "0.weight", {dim_int, ctx->C(), 1, 1}, PK_MAT_16);
+    for (int i = 0; i < layers; ++i) {
+        const int64_t in = i == 0 ? dim_int : dim_out;
+        add_slot(ctx, p + std::to_string(i + 1) + ".weight", {in, dim_out, 2, 2}, PK_CONVT_16);
+    }
+}
+
+const float* fptr(me_ctx* ctx, const std::string& name) {
+    auto it = ctx->slot_by_name.find(name);
+    ME_CHECK(it != ctx->slot_by_name.end(), ME_ERR_BAD_ARG, "internal: no slot %s", name.c_str());
+    return reinterpret_cast<const float*>(ctx->arena + ctx->slots[it->second].offset);
+}
+const void* vptr(me_ctx* ctx, const std::string& name) { return fptr(ctx, name); }
+
+void resolve_vit(me_ctx* ctx, const std::string& p, VitW& v) {
+    v.patch_w = vptr(ctx, p + "patch_embed.proj.weight");
+    v.patch_b = fptr(ctx, p + "patch_embed.proj.bias");
+    v.cls = fptr(ctx, p + "cls_token");
+    v.pos = fptr(ctx, p + "pos_embed");
+    v.norm_w = fptr(ctx, p + "norm.weight");
+    v.norm_b = fptr(ctx, p + "norm.bias");
+    v.blocks.resize(ctx->cfg.depth);
+    for (int i = 0; i < ctx->cfg.depth; ++i) {
+        const std::string b = p + "blocks." + std::to_string(i) + ".";
+        VitBlockW& w = v.blocks[i];
+        w.ln1_w = fptr(ctx, b + "norm1.weight"), w.ln1_b = fptr(ctx, b + "norm1.bias");
+        w.qkv_w = vptr(ctx, b + "attn.qkv.weight"), w.qkv_b = fptr(ctx, b + "attn.qkv.bias");
+        w.proj_w = vptr(ctx, b + "attn.proj.weight"), w.proj_b = fptr(ctx, b + "attn.proj.bias");
+        w.ls1 = fptr(ctx, b + "ls1.gamma");
+        w.ln2_w = fptr(ctx, b + "norm2.weight"), w.ln2_b = fptr(ctx, b + "norm2.bias");
+        w.fc1_w = vptr(ctx, b + "mlp.fc1.weight"), w.fc1_b = fptr(ctx, b + "mlp.fc1.bias");
+        w.fc2_w = vptr(ctx, b + "mlp.fc2.weight"), w.fc2_b = fptr(ctx, b + "mlp.fc2.bias");
+        w.ls2 = fptr(ctx, b + "ls2.gamma");
+    }
+}
+
+void resolve_upsample(me_ctx* ctx, const std::string& p, int64_t dim_out, int layers,
+                      int64_t dim_int, UpsampleW& u) {
+    u.conv = vptr(ctx, p + "0.weight");
+    u.dim_int = (int)dim_int;
+    u.convt.clear(), u.cin.clear(), u.cout.clear();
+    for (int i = 0; i < layers; ++i) {
+        u.convt.push_back(vptr(ctx, p + std::to_string(i + 1) + ".weight"));
+        u.cin.push_back((int)(i == 0 ? dim_int : dim_out));
+        u.cout.push_back((int)dim_out);
+    }
+}
+
+// IEEE half <-> float on the host (no dependence on compiler half support in host code paths)
+inline float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {
+            int e = -1;
+            do {
+                ++e;
+                man <<= 1;
+            } while (!(man & 0x400));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ff) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+inline uint16_t float_to_half(float f) {
+    _Float16 h = (_Float16)f;  // round to nearest even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline uint16_t float_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16);
+}
+
+struct HostSrc {
+    const void* p;
+    int32_t dt;
+    float get(int64_t i) const {
+        return dt == ME_WEIGHT_F32 ? ((const float*)p)[i] : half_to_float(((const uint16_t*)p)[i]);
+    }
+};
+
+}  // namespace
+
+void build_weight_table(me_ctx* ctx) {
+    const me_model_config& c = ctx->cfg;
+    const int64_t C = c.embed_dim, dec = c.dec_dim;
+    const int64_t e0 = c.enc_dims[0], e1 = c.enc_dims[1], e2 = c.enc_dims[2], e3 = c.enc_dims[3];
+    ctx->slots.clear();
+    ctx->slot_by_name.clear();
+    ctx->arena_bytes = 0;
+    add_vit(ctx, "encoder.patch_encoder.");
+    add_vit(ctx, "encoder.image_encoder.");
+    // encoder.rs:48-71
+    add_upsample(ctx, "encoder.upsample_latent0.", dec, 3, e0);
+    add_upsample(ctx, "encoder.upsample_latent1.", e0, 2, e0);
+    add_upsample(ctx, "encoder.upsample0.", e1, 1, e1);
+    add_upsample(ctx, "encoder.upsample1.", e2, 1, e2);
+    add_upsample(ctx, "encoder.upsample2.", e3, 1, e3);
+    add_slot(ctx, "encoder.upsample_lowres.weight", {C, e3, 2, 2}, PK_CONVT_16);
+    add_slot(ctx, "encoder.upsample_lowres.bias", {e3}, PK_VEC_F32);
+    add_slot(ctx, "encoder.fuse_lowres.weight", {e3, 2 * e3, 1, 1}, PK_MAT_16);
+    add_slot(ctx, "encoder.fuse_lowres.bias", {e3}, PK_VEC_F32);
+    // decoder.rs:115-146; dims_encoder = [dec, e0, e1, e2, e3] (mod.rs:293-295).  PyTorch keeps an
+    // Identity at convs.0 when dims_encoder[0] == dim_decoder, so the file's keys start at convs.1
+    const int64_t dims_enc[5] = {dec, e0, e1, e2, e3};
+    ME_CHECK(dims_enc[0] == dec, ME_ERR_BAD_SHAPE, "decoder: dims_encoder[0] != dim_decoder");
+    for (int i = 1; i < 5; ++i)
+        add_slot(ctx, "decoder.convs." + std::to_string(i) + ".weight", {dec, dims_enc[i], 3, 3},
+                 PK_CONV_16);
+    for (int i = 0; i < 5; ++i) {
+        const std::string f = "decoder.fusions." + std::to_string(i) + ".";
+        for (const char* rn : {"resnet1", "resnet2"})
+            for (const char* idx : {"1", "3"}) {
+                add_slot(ctx, f + rn + ".residual." + idx + ".weight", {dec, dec, 3, 3}, PK_CONV_16);
+                add_slot(ctx, f + rn + ".residual." + idx + ".bias", {dec}, PK_VEC_F32);
+            }
+        if (i != 0) add_slot(ctx, f + "deconv.weight", {dec, dec, 2, 2}, PK_CONVT_16);
+        add_slot(ctx, f + "out_conv.weight", {dec, dec, 1, 1}, PK_MAT_16);
+        add_slot(ctx, f + "out_conv.bias", {dec}, PK_VEC_F32);
+    }
+    // mod.rs:57-97 (PyTorch Sequential indices 0,1,2,4: index 3 is the ReLU)
+    add_slot(ctx, "head.0.weight", {dec / 2, dec, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "head.0.bias", {dec / 2}, PK_VEC_F32);
+    add_slot(ctx, "head.1.weight", {dec / 2, dec / 2, 2, 2}, PK_CONVT_16);
+    add_slot(ctx, "head.1.bias", {dec / 2}, PK_VEC_F32);
+    add_slot(ctx, "head.2.weight", {c.head_dims[0], dec / 2, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "head.2.bias", {c.head_dims[0]}, PK_VEC_F32);
+    add_slot(ctx, "head.4.weight", {c.head_dims[1], c.head_dims[0], 1, 1}, PK_VEC_F32);
+    add_slot(ctx, "head.4.bias", {c.head_dims[1]}, PK_VEC_F32);
+    // fov.rs:95-128
+    add_vit(ctx, "fov.encoder.0.");
+    add_slot(ctx, "fov.encoder.1.weight", {dec / 2, C}, PK_MAT_16);
+    add_slot(ctx, "fov.encoder.1.bias", {dec / 2}, PK_VEC_F32);
+    add_slot(ctx, "fov.downsample.0.weight", {dec / 2, dec, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "fov.downsample.0.bias", {dec / 2}, PK_VEC_F32);
+    add_slot(ctx, "fov.head.0.weight", {dec / 4, dec / 2, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "fov.head.0.bias", {dec / 4}, PK_VEC_F32);
+    add_slot(ctx, "fov.head.2.weight", {dec / 8, dec / 4, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "fov.head.2.bias", {dec / 8}, PK_VEC_F32);
+    const int64_t k = c.grid / 4;  // 6 for grid 24 (fov.rs:115)
+    add_slot(ctx, "fov.head.4.weight", {1, dec / 8, k, k}, PK_CONVK_F32);
+    add_slot(ctx, "fov.head.4.bias", {1}, PK_VEC_F32);
+}
+
+void resolve_weights(me_ctx* ctx) {
+    const me_model_config& c = ctx->cfg;
+    ModelW& w = ctx->w;
+    resolve_vit(ctx, "encoder.patch_encoder.", w.vit[ME_VIT_PATCH_ENCODER]);
+    resolve_vit(ctx, "encoder.image_encoder.", w.vit[ME_VIT_IMAGE_ENCODER]);
+    resolve_vit(ctx, "fov.encoder.0.", w.vit[ME_VIT_FOV_ENCODER]);
+    resolve_upsample(ctx, "encoder.upsample_latent0.", c.dec_dim, 3, c.enc_dims[0], w.up_latent0);
+    resolve_upsample(ctx, "encoder.upsample_latent1.", c.enc_dims[0], 2, c.enc_dims[0], w.up_latent1);
+    resolve_upsample(ctx, "encoder.upsample0.", c.enc_dims[1], 1, c.enc_dims[1], w.up0);
+    resolve_upsample(ctx, "encoder.upsample1.", c.enc_dims[2], 1, c.enc_dims[2], w.up1);
+    resolve_upsample(ctx, "encoder.upsample2.", c.enc_dims[3], 1, c.enc_dims[3], w.up2);
+    w.up_lowres_w = vptr(ctx, "encoder.upsample_lowres.weight");
+    w.up_lowres_b = fptr(ctx, "encoder.upsample_lowres.bias");
+    w.fuse_w = vptr(ctx, "encoder.fuse_lowres.weight");
+    w.fuse_b = fptr(ctx, "encoder.fuse_lowres.bias");
+    w.dec_convs[0] = nullptr;
+    for (int i = 1; i < 5; ++i)
+        w.dec_convs[i] = vptr(ctx, "decoder.convs." + std::to_string(i) + ".weight");
+    for (int i = 0; i < 5; ++i) {
+        const std::string f = "decoder.fusions." + std::to_string(i) + ".";
+        FusionW& fw = w.fusions[i];
+        RcuW* rc[2] = {&fw.resnet1, &fw.resnet2};
+        const char* rn[2] = {"resnet1", "resnet2"};
+        const char* idx[2] = {"1", "3"};
+        for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 2; ++k) {
+                rc[r]->w[k] = vptr(ctx, f + rn[r] + ".residual." + idx[k] + ".weight");
+                rc[r]->b[k] = fptr(ctx, f + rn[r] + ".residual." + idx[k] + ".bias");
+            }
+        fw.deconv = i != 0 ? vptr(ctx, f + "deconv.weight") : nullptr;
+        fw.out_w = vptr(ctx, f + "out_conv.weight");
+        fw.out_b = fptr(ctx, f + "out_conv.bias");
+    }
+    w.head0_w = vptr(ctx, "head.0.weight"), w.head0_b = fptr(ctx, "head.0.bias");
+    w.head1_w = vptr(ctx, "head.1.weight"), w.head1_b = fptr(ctx, "head.1.bias");
+    w.head2_w = vptr(ctx, "head.2.weight"), w.head2_b = fptr(ctx, "head.2.bias");
+    w.head4_w = fptr(ctx, "head.4.weight"), w.head4_b = fptr(ctx, "head.4.bias");
+    w.fov_lin_w = vptr(ctx, "fov.encoder.1.weight"), w.fov_lin_b = fptr(ctx, "fov.encoder.1.bias");
+    w.fov_down_w = vptr(ctx, "fov.downsample.0.weight");
+    w.fov_down_b = fptr(ctx, "fov.downsample.0.bias");
+    w.fov_h0_w = vptr(ctx, "fov.head.0.weight"), w.fov_h0_b = fptr(ctx, "fov.head.0.bias");
+    w.fov_h2_w = vptr(ctx, "fov.head.2.weight"), w.fov_h2_b = fptr(ctx, "fov.head.2.bias");
+    w.fov_h4_w = fptr(ctx, "fov.head.4.weight"), w.fov_h4_b = fptr(ctx, "fov.head.4.bias");
+}
+
+void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight_dtype,
+                 const int64_t* dims, int32_t ndim) {
+    ME_CHECK(name && data && dims, ME_ERR_BAD_ARG, "me_load_weight: null argument");
+    ME_CHECK(weight_dtype == ME_WEIGHT_F32 || weight_dtype == ME_WEIGHT_F16, ME_ERR_BAD_ARG,
+             "me_load_weight: bad weight dtype %d", weight_dtype);
+    auto it = ctx->slot_by_name.find(name);
+    ME_CHECK(it != ctx->slot_by_name.end(), ME_ERR_BAD_WEIGHT, "unexpected tensor '%s'", name);
+    WeightSlot& s = ctx->slots[it->second];
+    bool same = (int)s.dims.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = s.dims[i] == dims[i];
+    if (!same) {
+        std::string got, want;
+        for (int i = 0; i < ndim; ++i) got += (i ? "," : "") + std::to_string(dims[i]);
+        for (size_t i = 0; i < s.dims.size(); ++i) want += (i ? "," : "") + std::to_string(s.dims[i]);
+        fail(ME_ERR_BAD_WEIGHT, "tensor '%s' has shape [%s], expected [%s]", name, got.c_str(),
+             want.c_str());
+    }
+    const int64_t n = s.numel();
+    const size_t src_bytes = (size_t)n * (weight_dtype == ME_WEIGHT_F32 ? 4 : 2);
+    std::vector<char> staged;
+    if (is_device_ptr(data)) {
+        staged.resize(src_bytes);
+        ME_HIP(hipMemcpy(staged.data(), data, src_bytes, hipMemcpyDeviceToHost));
+        data = staged.data();
+    }
+    const HostSrc src{data, weight_dtype};
+    std::vector<char> packed(s.bytes);
+    const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
+    auto put16 = [&](int64_t dst, int64_t si) {
+        uint16_t* o = reinterpret_cast<uint16_t*>(packed.data());
+        if (!to_bf16 && weight_dtype == ME_WEIGHT_F16)
+            o[dst] = ((const uint16_t*)data)[si];  // fp16 checkpoint, f16 operands: exact
+        else
+            o[dst] = to_bf16 ? float_to_bf16(src.get(si)) : float_to_half(src.get(si));
+    };
+    switch (s.kind) {
+        case PK_VEC_F32: {
+            float* o = reinterpret_cast<float*>(packed.data());
+            if (weight_dtype == ME_WEIGHT_F32)
+                memcpy(o, data, (size_t)n * 4);
+            else
+                for (int64_t i = 0; i < n; ++i) o[i] = src.get(i);
+            break;
+        }
+        case PK_MAT_16:
+            if (!to_bf16 && weight_dtype == ME_WEIGHT_F16)
+                memcpy(packed.data(), data, (size_t)n * 2);
+            else
+                for (int64_t i = 0; i < n; ++i) put16(i, i);
+            break;
+        case PK_CONV_16: {  // [Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin]
+            const int64_t Cout = s.dims[0], Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
+            for (int64_t co = 0; co < Cout; ++co)
+                for (int64_t ci = 0; ci < Cin; ++ci)
+                    for (int64_t t = 0; t < kk; ++t)
+                        put16((co * kk + t) * Cin + ci, (co * Cin + ci) * kk + t);
+            break;
+        }
+        case PK_CONVT_16: {  // [Cin][Cout][2][2] -> [(dy*2+dx)*Cout + co][Cin]
+            const int64_t Cin = s.dims[0], Cout = s.dims[1];
+            for (int64_t ci = 0; ci < Cin; ++ci)
+                for (int64_t co = 0; co < Cout; ++co)
+                    for (int64_t q = 0; q < 4; ++q)
+                        put16((q * Cout + co) * Cin + ci, (ci * Cout + co) * 4 + q);
+            break;
+        }
+        case PK_CONVK_F32: {  // [1][Cin][k][k] -> f32 [k][k][Cin]
+            const int64_t Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
+            float* o = reinterpret_cast<float*>(packed.data());
+            for (int64_t ci = 0; ci < Cin; ++ci)
+                for (int64_t t = 0; t < kk; ++t) o[t * Cin + ci] = src.get(ci * kk + t);
+            break;
+        }
+    }
+    ME_HIP(hipMemcpy(ctx->arena + s.offset, packed.data(), s.bytes, hipMemcpyHostToDevice));
+    s.loaded = true;
+    ctx->finalized = false;
+}
+
+void finalize_weights(me_ctx* ctx) {
+    std::string missing;
+    int n = 0;
+    for (const WeightSlot& s : ctx->slots)
+        if (!s.loaded) {
+            if (n < 8) missing += (n ? ", " : "") + s.name;
+            ++n;
+        }
+    // LoaderError::RecorderMissing (mod.rs:241-243)
+    ME_CHECK(n == 0, ME_ERR_MISSING_WEIGHT, "%d tensors missing from the checkpoint: %s%s", n,
+             missing.c_str(), n > 8 ? ", ..." : "");
+    ctx->finalized = true;
+}
+
+}  // namespace me
