@@ -1,0 +1,191 @@
+"""Kernel-level parity (-m gpu): each HIP kernel, called through the C ABI
+(include/matrix_eyes_hip_ops.h), against a plain PyTorch fp32/fp64 evaluation of the same op on
+the same 16-bit-rounded operands.  Tolerances are written per test: f32 accumulation differences
+only (operands are identical), plus one rounding where the output is 16-bit."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import TORCH16, bordered, ctx_for, dev16, max_abs_rel, pack_conv, pack_convt, ptr, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f16", "bf16"]
+OUT_EPS = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}   # one rounding of a 16-bit output
+
+
+def _check(ctx, rc):
+    ctx._check(rc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, -1])
+@pytest.mark.parametrize("shape", [(577, 256, 128), (1000, 132, 192), (2309, 384, 256)])
+def test_linear(dtype, cfg, shape):
+    M, N, K = shape
+    ctx = ctx_for("tiny", dtype)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = dev16(torch.randn(M, K, generator=g), dtype)
+    w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    bias = torch.randn(N, generator=g).cuda()
+    out16 = torch.empty(M, N, dtype=TORCH16[dtype], device="cuda")
+    out32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(out16), ptr(out32), 0, cfg))
+    ctx.synchronize()
+    ref = a.double() @ w.double().T + bias.double()
+    assert max_abs_rel(out32, ref) < 2e-5          # f32 accumulation over K <= 256
+    assert max_abs_rel(out16.float(), ref) < 4 * OUT_EPS[dtype] * 4   # |x| up to ~4 rms
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_gelu(dtype):
+    M, N, K = 700, 512, 128
+    ctx = ctx_for("tiny", dtype)
+    g = torch.Generator().manual_seed(7)
+    a = dev16(torch.randn(M, K, generator=g) * 2, dtype)
+    w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    bias = torch.randn(N, generator=g).cuda()
+    out32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), None, ptr(out32), 1, -1))
+    ctx.synchronize()
+    ref = F.gelu(a.double() @ w.double().T + bias.double())     # exact erf form (vit.rs:121)
+    # A&S 7.1.26 erfc: abs error <= 1.5e-7 * |x| / 2, far below one f16 rounding of the output
+    assert float((out32.double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_linear_residual(dtype, cfg):
+    M, N, K = 1154, 256, 512
+    ctx = ctx_for("tiny", dtype)
+    g = torch.Generator().manual_seed(11)
+    a = dev16(torch.randn(M, K, generator=g), dtype)
+    w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    bias = torch.randn(N, generator=g).cuda()
+    gamma = (0.05 + 0.15 * torch.rand(N, generator=g)).cuda()
+    x = torch.randn(M, N, generator=g).cuda()
+    ref = x.double() + gamma.double() * (a.double() @ w.double().T + bias.double())
+    _check(ctx, ctx.lib.me_op_linear_residual(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x), cfg))
+    ctx.synchronize()
+    assert max_abs_rel(x, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tokens,windows,heads", [(577, 3, 2), (65, 5, 2), (577, 1, 16), (130, 2, 1)])
+def test_attention(dtype, tokens, windows, heads):
+    ctx = ctx_for("tiny", dtype)
+    C = heads * 64
+    g = torch.Generator().manual_seed(tokens + heads)
+    qkv = dev16(torch.randn(windows * tokens, 3 * C, generator=g) * 1.5, dtype)
+    out = torch.empty(windows * tokens, C, dtype=TORCH16[dtype], device="cuda")
+    _check(ctx, ctx.lib.me_op_attention(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+    ctx.synchronize()
+    x = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0] * 0.125, x[1], x[2]                       # vit.rs:63-71
+    ref = (torch.softmax(q @ k.transpose(3, 2), dim=3) @ v).transpose(1, 2).reshape(windows * tokens, C)
+    # P and the output are rounded to 16 bit once each
+    assert max_abs_rel(out.float(), ref) < 6 * OUT_EPS[dtype]
+    assert rel_l2(out.float(), ref) < 1.5 * OUT_EPS[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_large_scores(dtype):
+    """one key dominates from the middle of the sequence on: exercises the running-max rescale"""
+    ctx = ctx_for("tiny", dtype)
+    tokens, heads, C = 577, 1, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(tokens, 3 * C, generator=g)
+    x[300, C:2 * C] = x[17, 0:C] * 6.0       # key 300 aligned with query 17, score ~ 6*64/8
+    qkv = dev16(x, dtype)
+    out = torch.empty(tokens, C, dtype=TORCH16[dtype], device="cuda")
+    _check(ctx, ctx.lib.me_op_attention(ctx.handle, ptr(qkv), ptr(out), 1, tokens, heads))
+    ctx.synchronize()
+    xx = qkv.double()
+    q, k, v = xx[:, :C] * 0.125, xx[:, C:2 * C], xx[:, 2 * C:]
+    ref = torch.softmax(q @ k.T, dim=1) @ v
+    assert max_abs_rel(out.float(), ref) < 6 * OUT_EPS[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dim", [128, 1024])
+def test_layernorm(dtype, dim):
+    ctx = ctx_for("tiny", dtype)
+    rows = 1001
+    g = torch.Generator().manual_seed(dim)
+    x = (torch.randn(rows, dim, generator=g) * 3 + 0.5).cuda()
+    w = (1 + 0.02 * torch.randn(dim, generator=g)).cuda()
+    b = (0.02 * torch.randn(dim, generator=g)).cuda()
+    y32 = torch.empty_like(x)
+    y16 = torch.empty(rows, dim, dtype=TORCH16[dtype], device="cuda")
+    _check(ctx, ctx.lib.me_op_layernorm(ctx.handle, ptr(x), ptr(w), ptr(b), ptr(y16), ptr(y32), rows, dim, 1e-5))
+    ctx.synchronize()
+    ref = F.layer_norm(x.double(), (dim,), w.double(), b.double(), 1e-5)
+    assert float((y32.double() - ref).abs().max()) < 2e-5
+    assert float((y16.double() - ref).abs().max()) < 4 * OUT_EPS[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=24, W=24, Cin=64, Cout=128, k=3, stride=1),
+    dict(B=1, H=40, W=40, Cin=128, Cout=256, k=3, stride=1, res=True, relu=True),
+    dict(B=2, H=16, W=16, Cin=256, Cout=128, k=3, stride=2),
+    dict(B=1, H=12, W=12, Cin=64, Cout=32, k=3, stride=2),
+    dict(B=1, H=20, W=20, Cin=128, Cout=64, k=1, stride=1),
+])
+@pytest.mark.parametrize("cfg", [-1, 1, 2])
+def test_conv2d(dtype, case, cfg):
+    ctx = ctx_for("tiny", dtype)
+    B, H, W, Cin, Cout, k, s = (case[n] for n in ("B", "H", "W", "Cin", "Cout", "k", "stride"))
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    bias = torch.randn(Cout, generator=g)
+    xb = bordered(x, dtype)
+    w16 = dev16(pack_conv(w), dtype)
+    Ho, Wo = H // s, W // s
+    res = torch.randn(B * Ho * Wo, Cout, generator=g).cuda() if case.get("res") else None
+    res2 = torch.randn(B * Ho * Wo, Cout, generator=g).cuda() if case.get("res") else None
+    out32 = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32, device="cuda")
+    out16 = torch.zeros(B, Ho + 2, Wo + 2, Cout, dtype=TORCH16[dtype], device="cuda")
+    act = 2 if case.get("relu") else 0
+    _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, k, s, ptr(bias.cuda()),
+                                     ptr(res), ptr(res2), ptr(out32), ptr(out16), 1, act, 0, cfg))
+    ctx.synchronize()
+    x16 = xb[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).double().cpu()
+    w16f = dev16(w, dtype).double().cpu()
+    ref = F.conv2d(x16, w16f, bias.double(), stride=s, padding=(k - 1) // 2)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+    if res is not None:
+        ref = ref + res.double().cpu() + res2.double().cpu()
+    assert max_abs_rel(out32.cpu(), ref) < 3e-5
+    ref16 = F.relu(ref) if act else ref
+    got16 = out16[:, 1:Ho + 1, 1:Wo + 1, :].reshape(B * Ho * Wo, Cout).float().cpu()
+    assert max_abs_rel(got16, ref16) < 6 * OUT_EPS[dtype] * 4
+    # the zero border must stay zero
+    assert float(out16[:, 0].abs().max()) == 0 and float(out16[:, :, 0].abs().max()) == 0
+    assert float(out16[:, -1].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+def test_conv_transpose(dtype, cfg):
+    ctx = ctx_for("tiny", dtype)
+    B, H, W, Cin, Cout = 2, 18, 18, 128, 64
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin)
+    bias = torch.randn(Cout, generator=g)
+    x16 = dev16(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin), dtype)
+    w16 = dev16(pack_convt(w), dtype)
+    out32 = torch.empty(B, 2 * H, 2 * W, Cout, dtype=torch.float32, device="cuda")
+    out16 = torch.zeros(B, 2 * H + 2, 2 * W + 2, Cout, dtype=TORCH16[dtype], device="cuda")
+    _check(ctx, ctx.lib.me_op_conv_transpose2x2(ctx.handle, ptr(x16), B, H, W, Cin, ptr(w16), Cout,
+                                                ptr(bias.cuda()), ptr(out32), ptr(out16), 1, cfg))
+    ctx.synchronize()
+    xr = x16.double().cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(xr, dev16(w, dtype).double().cpu(), bias.double(), stride=2).permute(0, 2, 3, 1)
+    assert max_abs_rel(out32.cpu(), ref) < 2e-5
+    assert max_abs_rel(out16[:, 1:-1, 1:-1, :].float().cpu(), ref) < 6 * OUT_EPS[dtype] * 4
+    assert float(out16[:, 0].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
