@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — 1536x1536 depth-maps/sec of the HIP Depth Pro path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A step = one pass of the hot path (me_extract_depth_u8: preprocess ->
+encoder -> decoder -> FOV head -> depth head) over one batch of synthetic u8 images that already sit
+in HBM.  At N = 1 the workload is BASELINE.json configs[1] (a single 1536x1536 image, depth map +
+FOV head).  With N > 1 every rank runs the same per-GPU batch on its own images (weak scaling, image
+parallel, no collective in the timed loop); rank 0 builds the synthetic checkpoint and ships the
+packed weight arena to the others with ONE RCCL broadcast before the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the step
+(measured live with HIP events on the launch stream); `cpu_baseline` is the CPU oracle timed on this
+box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per 1536x1536 image (SURVEY.md §8d / App. B, 2*M*N*K convention)
+TFLOP_PER_IMAGE_FOV = 19.247
+TFLOP_PER_IMAGE_NOFOV = 18.865
+VIT_WINDOW_GFLOP = 382.13
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-fov", action="store_true", help="pass f_norm = 1 instead of the FOV head")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=1,
+                    help="ViT windows of the oracle sample timed for cpu_baseline")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, weights, windows):
+    """The oracle's patch-encoder ViT-L over `windows` of the image's 35 windows, on the host cores;
+    scaled to images/s by its share of the image's algorithmic FLOPs."""
+    import torch
+    from oracle import depth_pro_oracle as O
+    ocfg = O.OracleConfig(grid=cfg.grid, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads,
+                          depth=cfg.depth, tap_blocks=tuple(cfg.tap_blocks), enc_dims=tuple(cfg.enc_dims),
+                          dec_dim=cfg.dec_dim, head_dims=tuple(cfg.head_dims))
+    g = torch.Generator().manual_seed(1234)
+
+    def run(n):
+        xs = torch.rand(n, 3, cfg.window, cfg.window, generator=g) * 2 - 1
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.vit_forward_features(xs, weights, "encoder.patch_encoder.", ocfg, list(cfg.tap_blocks))
+            return time.perf_counter() - t0
+
+    dt = run(windows)
+    if dt < 8.0:      # aim at 10-30 s of CPU work
+        windows = int(min(35, max(windows + 1, round(windows * 15.0 / dt))))
+        dt = run(windows)
+    share = windows * VIT_WINDOW_GFLOP / 1e3 / TFLOP_PER_IMAGE_FOV
+    return {
+        "value": share / dt,
+        "unit": "depth-maps/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": (f"CPU oracle (PyTorch fp32 restatement of the reference; Burn-ndarray cannot be built "
+                   f"here): patch-encoder ViT-L over {windows} of 35 windows = "
+                   f"{windows * VIT_WINDOW_GFLOP:.0f} GFLOP = {share * 100:.2f}% of one image's "
+                   f"{TFLOP_PER_IMAGE_FOV} TFLOP, {dt:.1f} s; scaled by that share"),
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import matrix_eyes_amd as m
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes "
+                         f"(WORLD_SIZE={world})")
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    cfg = m.ModelConfig()
+    ctx = m.Context(local_rank, args.dtype, cfg)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    # ---- weights: rank 0 parses/packs, one RCCL broadcast of the arena
+    weights = None
+    t_load = time.perf_counter()
+    if rank == 0:
+        weights = synthetic_checkpoint(cfg)          # seed 2024; real depth_pro.pt is not available offline
+        ctx.load_state_dict(weights)
+    if distributed:
+        ids = [ctx.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.bcast_weights(ids[0], rank, world)
+    t_load = time.perf_counter() - t_load
+
+    # ---- inputs resident in HBM before the timed region
+    S, B = cfg.img_size, args.batch
+    rgb = torch.from_numpy(synthetic_images(B, S, "structured", seed=4321 + rank)).cuda()
+    depth = torch.empty(B, S, S, dtype=torch.float32, device="cuda")
+    f_norm = 1.0 if args.no_fov else None
+
+    def step():
+        ctx.extract_depth(rgb, f_norm, out=depth)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ctx.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile_enable(False)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(depth).all()), "non-finite depth"
+
+    if rank == 0:
+        images = world * B * args.steps
+        value = images / elapsed
+        tflop_img = TFLOP_PER_IMAGE_NOFOV if args.no_fov else TFLOP_PER_IMAGE_FOV
+        # dominant kernel: largest total time over the timed region
+        dom = max(prof, key=lambda k: k["total_ms"])
+        dom_ms = dom["total_ms"] / dom["launches"]
+        achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3) / 1e12
+        step_ms = elapsed / args.steps * 1e3
+        kernels = sorted(prof, key=lambda k: -k["total_ms"])
+        out = {
+            "metric": "1536x1536 depth-maps/sec",
+            "value": round(value, 3),
+            "unit": "depth-maps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(step_ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE.json configs[1]: single 1536x1536 image, 16-bit MFMA HIP path on "
+                             "1xMI355X, depth map + FOV head" if (B == 1 and not args.no_fov) else
+                             f"{B} x 1536x1536 images per GPU per step, " +
+                             ("f_norm given" if args.no_fov else "FOV head")),
+                "batch_per_gpu": B,
+                "images": "u8 [B,1536,1536,3] synthetic 'structured' (seed 4321 + rank), resident in HBM",
+                "checkpoint": "synthetic, seed 2024, exact key set, 951.99 M parameters rounded to fp16",
+                "f_norm": "1.0" if args.no_fov else "FOV head (mod.rs:343-358)",
+                "parallelism": f"image-parallel, {world} process(es), one per GPU; weights by one RCCL "
+                               f"broadcast at start-up ({t_load:.1f} s incl. synthetic init)",
+                "tflop_per_image": tflop_img,
+                "model_tflops": round(value * tflop_img, 1),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": dom["kernel"],
+                "launches_per_step": dom["launches"] / args.steps,
+                "avg_launch_ms": round(dom_ms, 5),
+                "achieved": round(achieved, 1),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "share_of_step": round(dom["total_ms"] / (elapsed * 1e3), 3),
+                "whole_step_frac": round(value / world * tflop_img / MFMA_PEAK_TFLOPS, 4),
+            },
+            "kernels": [{"kernel": k["kernel"], "launches_per_step": k["launches"] / args.steps,
+                         "ms_per_step": round(k["total_ms"] / args.steps, 4),
+                         "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1) if k["flops"] else None}
+                        for k in kernels[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_windows)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

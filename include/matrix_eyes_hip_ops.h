@@ -49,6 +49,11 @@ int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_
 /* f32 <-> context 16-bit type */
 int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
 int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): enable(1)
+   clears and starts recording, report() synchronises and writes a JSON array of
+   {"kernel", "launches", "total_ms", "flops", "bytes"} (algorithmic work, summed over launches). */
+int32_t me_profile_enable(me_ctx* ctx, int32_t on);
+int32_t me_profile_report(me_ctx* ctx, char* json, int64_t capacity);
 /* Names of the GEMM tile configurations (for reports). */
 int32_t me_op_gemm_config_count(void);
 const char* me_op_gemm_config_name(int32_t cfg);

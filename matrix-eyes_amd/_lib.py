@@ -76,6 +76,8 @@ SIGNATURES = {
                                        _i32, _i32]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),
     "me_op_cast_to32": (_i32, [_vp, _vp, _vp, _i64]),
+    "me_profile_enable": (_i32, [_vp, _i32]),
+    "me_profile_report": (_i32, [_vp, C.c_char_p, _i64]),
     "me_op_gemm_config_count": (_i32, []),
     "me_op_gemm_config_name": (C.c_char_p, [_i32]),
 }

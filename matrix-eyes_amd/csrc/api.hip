@@ -611,6 +611,52 @@ int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t coun
     ME_API_END(ctx)
 }
 
+int32_t me_profile_enable(me_ctx* ctx, int32_t on) {
+    ME_API_BEGIN(ctx)
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    Profiler& p = profiler();
+    for (ProfEntry& e : p.entries) {
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+    p.entries.clear();
+    p.enabled = on != 0;
+    ME_API_END(ctx)
+}
+
+int32_t me_profile_report(me_ctx* ctx, char* json, int64_t capacity) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(json && capacity > 2, ME_ERR_BAD_ARG, "me_profile_report: no buffer");
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    struct Agg {
+        double ms = 0, flops = 0, bytes = 0;
+        long count = 0;
+    };
+    std::map<std::string, Agg> agg;
+    for (ProfEntry& e : profiler().entries) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
+        Agg& a = agg[e.name];
+        a.ms += ms, a.flops += e.flops, a.bytes += e.bytes, a.count += 1;
+    }
+    std::string out = "[";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[512];
+        snprintf(line, sizeof line,
+                 "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, "
+                 "\"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops,
+                 kv.second.bytes);
+        out += line;
+        first = false;
+    }
+    out += "]";
+    ME_CHECK((int64_t)out.size() + 1 <= capacity, ME_ERR_BAD_ARG, "me_profile_report: buffer too small");
+    memcpy(json, out.c_str(), out.size() + 1);
+    ME_API_END(ctx)
+}
+
 int32_t me_op_gemm_config_count(void) { return gemm_num_configs(); }
 const char* me_op_gemm_config_name(int32_t cfg) { return gemm_config_name(cfg); }
 

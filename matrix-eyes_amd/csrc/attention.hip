@@ -235,6 +235,7 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
              "attention: windows=%d tokens=%d heads=%d", windows, tokens, heads);
     ME_CHECK(heads <= 65535 && windows <= 65535, ME_ERR_BAD_SHAPE, "attention: grid too large");
     const dim3 grid((tokens + 127) / 128, heads, windows);
+    ProfScope prof(stream, "attention_kernel", 4.0 * windows * heads * (double)tokens * tokens * 64, 0.0);
     // scale = 1/sqrt(64) (vit.rs:47), folded with log2(e) so the softmax runs on exp2
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == ME_DTYPE_F16)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/matrix_eyes_hip.h"
 
@@ -47,6 +48,27 @@ struct Error {
     } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; when on, every instrumented launch is bracketed by two events.
+// ---------------------------------------------------------------------------------------
+struct ProfEntry {
+    std::string name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+struct Profiler {
+    bool enabled = false;
+    std::vector<ProfEntry> entries;
+};
+Profiler& profiler();
+struct ProfScope {
+    hipStream_t stream;
+    int index = -1;
+    ProfScope(hipStream_t s, const std::string& name, double flops, double bytes);
+    ~ProfScope();
+};
 
 // ---------------------------------------------------------------------------------------
 // GEMM / implicit-GEMM convolution: D[m][n] = sum_k A(m,k) * W[n][k]  (+ epilogue).

@@ -464,6 +464,7 @@ void layernorm_launch(const float* x, const float* w, const float* b, void* y16,
                       int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream) {
     ME_CHECK(dim % 64 == 0 && rows > 0, ME_ERR_BAD_SHAPE, "layernorm: rows=%lld dim=%d",
              (long long)rows, dim);
+    ProfScope prof(stream, "layernorm_kernel", 0.0, (double)rows * dim * (4 + (y16 ? 2 : 0) + (y32 ? 4 : 0)));
     ME_BY_DTYPE(dtype, layernorm_typed<f16>(x, w, b, y16, y32, rows, dim, eps, stream),
                 layernorm_typed<bf16>(x, w, b, y16, y32, rows, dim, eps, stream));
 }

@@ -33,6 +33,24 @@ ME_DECL(bf16, A_CONV, EPI_STORE)
 ME_DECL(bf16, A_CONV, EPI_HEAD_FINAL)
 #undef ME_DECL
 
+Profiler& profiler() {
+    static thread_local Profiler p;
+    return p;
+}
+ProfScope::ProfScope(hipStream_t s, const std::string& name, double flops, double bytes) : stream(s) {
+    Profiler& p = profiler();
+    if (!p.enabled) return;
+    ProfEntry e;
+    e.name = name, e.flops = flops, e.bytes = bytes;
+    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+    (void)hipEventRecord(e.e0, stream);
+    index = (int)p.entries.size();
+    p.entries.push_back(e);
+}
+ProfScope::~ProfScope() {
+    if (index >= 0) (void)hipEventRecord(profiler().entries[index].e1, stream);
+}
+
 static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w"};
 int gemm_num_configs() { return 4; }
 const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 4 ? kCfgNames[cfg] : "?"; }
@@ -86,6 +104,12 @@ void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, h
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
     const int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N);
+    static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
+    ProfScope prof(stream,
+                   std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +
+                       (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg)) + "," +
+                       (amode == A_PLAIN ? "plain" : "conv") + "," + kEpi[epi] + ">",
+                   2.0 * p.M * p.N * p.K, 0.0);
     if (dtype == ME_DTYPE_F16)
         launch_typed<f16>(p, amode, epi, cfg, stream);
     else if (dtype == ME_DTYPE_BF16)

@@ -95,6 +95,15 @@ class Context:
         self._progress_ref = cb
         self._check(self.lib.me_ctx_set_progress(self._h, cb, None))
 
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.me_profile_enable(self._h, 1 if on else 0))
+
+    def profile_report(self):
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self.lib.me_profile_report(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     # -- weights (mod.rs:174-249 load_record)
     def expected_weights(self):
         n = self.lib.me_expected_weight_count(self._h)

@@ -70,6 +70,14 @@ def max_abs_rel(a, b) -> float:
     return float((a - b).abs().max() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 
 
+def max_err_over_max(a, b) -> float:
+    """max |a-b| / max |b|: worst element against the largest magnitude (what one rounding of a
+    16-bit output is proportional to)"""
+    a = torch.as_tensor(a, dtype=torch.float64).flatten()
+    b = torch.as_tensor(b, dtype=torch.float64).flatten()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
 def pack_conv(w: torch.Tensor) -> torch.Tensor:
     """[Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin] (csrc/weights.hip PK_CONV_16)"""
     co, ci, kh, kw = w.shape

@@ -33,7 +33,9 @@ def main():
     dtype = sys.argv[1] if len(sys.argv) > 1 else "f16"
     t16 = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
     ctx = m.Context(0, dtype, m.ModelConfig.tiny())
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream()   # a real stream: handle 0 would select the context's own stream
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     lib, h = ctx.lib, ctx.handle
     res = []
     M = 35 * 577
