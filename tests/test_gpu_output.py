@@ -1,0 +1,220 @@
+"""Output back end parity (-m gpu): the HIP kernels behind me_depth_clamp_minmax / me_stereogram /
+me_depthmap_rgb / me_mesh_index / me_mesh_vertices / me_output_mesh, through the C ABI, BIT-EXACT
+against the C oracle (oracle/output_oracle.c), the hand-derived known answers, and size-independent
+properties at the full 1536x1536 size."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import matrix_eyes_amd as m
+from oracle import output_oracle as OO
+from util import ctx_for
+
+pytestmark = pytest.mark.gpu
+KA = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "output_known_answers.json")))
+
+
+def _ctx():
+    return ctx_for("tiny", "f16")
+
+
+def _depth(n, seed=0, kind="scene"):
+    """inverse-depth-like maps: smooth background + a few nearer rectangles (discontinuities)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, n, dtype=np.float32), np.linspace(0, 1, n, dtype=np.float32),
+                         indexing="ij")
+    d = 0.2 + 0.15 * np.sin(3 * xx + 2 * yy) + 0.1 * yy
+    if kind == "scene":
+        for _ in range(6):
+            x0, y0 = rng.integers(0, n - n // 4, size=2)
+            w, h = rng.integers(n // 16, n // 4, size=2)
+            d[y0:y0 + h, x0:x0 + w] += rng.uniform(0.2, 1.5)
+        d += rng.normal(0, 0.002, size=d.shape).astype(np.float32)
+    return np.ascontiguousarray(d.astype(np.float32))
+
+
+def test_known_answers():
+    ctx = _ctx()
+    c = KA["clamp"]
+    dm = m.DepthMap(ctx, np.array(c["input"], np.float32).reshape(1, -1), (5, 1))
+    assert dm.data.flatten().tolist() == np.array(c["clamped"], np.float32).tolist()
+    assert dm.inverse_depth_range() == (np.float32(c["min"]), np.float32(c["max"]))
+
+    c = KA["stereogram_step"]
+    dm = m.DepthMap(ctx, np.array(c["depth"], np.float32), (c["out_w"], c["out_h"]))
+    noise = np.arange(c["out_w"] * c["out_h"] * 3, dtype=np.uint8).reshape(c["out_h"], c["out_w"], 3)
+    out = dm.stereogram(None, c["amplitude"], noise)
+    assert np.array_equal(out[0], noise[0][c["source_index"]])
+
+    c = KA["stereogram_flat"]
+    dm = m.DepthMap(ctx, np.array(c["depth"], np.float32), (c["out_w"], c["out_h"]))
+    noise = np.random.default_rng(5).integers(0, 256, size=(c["out_h"], c["out_w"], 3), dtype=np.uint8)
+    out = dm.stereogram(None, c["amplitude"], noise)
+    for y in range(c["out_h"]):
+        assert np.array_equal(out[y], noise[y][np.arange(c["out_w"]) % c["pattern_width"]])
+
+    c = KA["mesh_3x3"]
+    dm = m.DepthMap(ctx, np.array(c["depth"], np.float32), (3, 3))
+    vi, nv, faces = dm.mesh_index()
+    assert vi.tolist() == c["vertex_index"] and nv == c["nvertices"] and faces.tolist() == c["faces"]
+
+    for which in ("keep", "drop"):
+        c = KA["mesh_threshold"][which]
+        a = struct.unpack("<f", struct.pack("<I", int(c["a_bits"], 16)))[0]
+        dm = m.DepthMap(ctx, np.array([[1.0, a], [1.0, 1.0]], np.float32), (2, 2))
+        assert len(dm.mesh_index()[2]) == c["nfaces"]
+
+    c = KA["colormap"]
+    dm = m.DepthMap(ctx, np.array(c["depth"], np.float32).reshape(1, -1), (2, 1))
+    assert dm.depth_map_rgb().reshape(-1, 3).tolist() == c["rgb"]
+
+
+@pytest.mark.parametrize("n,out_size,amplitude", [
+    (1536, None, 1.0 / 16.0),          # BASELINE config 5 geometry
+    (512, (640, 480), 1.0 / 16.0),     # non-square original size
+    (512, (1001, 777), 0.125),
+    (256, (300, 200), 0.01),           # small pattern
+    (64, (40, 30), 0.0005),            # degenerate: pattern_width rounds to 0
+])
+def test_stereogram_bit_exact(n, out_size, amplitude):
+    ctx = _ctx()
+    d = _depth(n, seed=n)
+    size = out_size or (n, n)
+    dm = m.DepthMap(ctx, d, size)
+    od, mn, mx = OO.clamp_minmax(d)
+    assert np.array_equal(dm.data, od) and dm.inverse_depth_range() == (mn, mx)
+    noise = np.random.default_rng(99).integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8)
+    got = dm.stereogram(None, amplitude, noise)
+    want = OO.stereogram(od, mn, mx, size[0], size[1], amplitude, noise)
+    assert np.array_equal(got, want)
+
+
+def test_stereogram_resize_scale():
+    ctx = _ctx()
+    d = _depth(512, seed=3)
+    dm = m.DepthMap(ctx, d, (801, 603))
+    w, h = dm.stereogram_size(0.37)
+    assert (w, h) == (296, 223)        # round(801*0.37) = round(296.37), round(603*0.37) = round(223.11)
+    noise = np.random.default_rng(1).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    got = dm.stereogram(0.37, 1.0 / 16.0, noise)
+    od, mn, mx = OO.clamp_minmax(d)
+    assert np.array_equal(got, OO.stereogram(od, mn, mx, w, h, 1.0 / 16.0, noise))
+
+
+def test_clamp_with_outliers_and_device_pointer():
+    import torch
+    ctx = _ctx()
+    d = _depth(700, seed=11)
+    d[5, 7], d[100, 3], d[8, 8] = 1e-4, 1e4, 0.0041
+    od, mn, mx = OO.clamp_minmax(d)
+    dm = m.DepthMap(ctx, d, (700, 700))
+    assert np.array_equal(dm.data, od) and dm.inverse_depth_range() == (mn, mx)
+    t = torch.from_numpy(d).cuda()
+    import ctypes as C
+    a, b = C.c_float(), C.c_float()
+    ctx._check(ctx.lib.me_depth_clamp_minmax(ctx.handle, C.c_void_p(t.data_ptr()), t.numel(), C.byref(a), C.byref(b)))
+    assert np.array_equal(t.cpu().numpy(), od) and (a.value, b.value) == (mn, mx)
+
+
+@pytest.mark.parametrize("n", [1536, 333])
+def test_depthmap_rgb_bit_exact(n):
+    ctx = _ctx()
+    d = _depth(n, seed=n + 1)
+    dm = m.DepthMap(ctx, d, (n, n))
+    od, mn, mx = OO.clamp_minmax(d)
+    assert np.array_equal(dm.depth_map_rgb(), OO.depthmap_rgb(od, mn, mx))
+
+
+@pytest.mark.parametrize("n,kind", [(1536, "scene"), (257, "scene"), (64, "smooth")])
+def test_mesh_index_and_vertices_bit_exact(n, kind):
+    ctx = _ctx()
+    d = _depth(n, seed=n + 2, kind=kind)
+    dm = m.DepthMap(ctx, d, (n * 2, n))
+    od, _, _ = OO.clamp_minmax(d)
+    vi, nv, faces = dm.mesh_index()
+    ovi, onv, ofaces = OO.mesh_index(od)
+    assert nv == onv and np.array_equal(vi, ovi) and np.array_equal(faces, ofaces)
+    assert 0 < len(faces) < 2 * (n - 1) * (n - 1) or kind == "smooth"
+    uv, xyz = dm.mesh_vertices(vi, nv)
+    ouv, oxyz = OO.mesh_vertices(od, ovi, onv, (n * 2, n))
+    assert np.array_equal(uv, ouv) and np.array_equal(xyz, oxyz)
+    # counting only (faces == NULL)
+    _, nv2, nf2 = dm.mesh_index(want_faces=False)
+    assert (nv2, nf2) == (nv, len(faces))
+
+
+def test_full_grid_mesh_closed_form_at_full_size():
+    ctx = _ctx()
+    n = 1536
+    dm = m.DepthMap(ctx, np.full((n, n), 0.7, np.float32), (n, n))
+    vi, nv, faces = dm.mesh_index()
+    assert nv == n * n and len(faces) == 2 * (n - 1) * (n - 1)
+    vi = vi.reshape(n, n)
+    assert np.array_equal(vi[0], np.concatenate([[0], 2 * np.arange(1, n)]))
+    assert np.array_equal(vi[1], np.concatenate([[1], 2 * np.arange(1, n) + 1]))
+    assert np.array_equal(vi[2:], (2 * n + np.arange((n - 2) * n)).reshape(n - 2, n))
+    # every face references valid, distinct vertices
+    assert faces.min() == 0 and faces.max() == nv - 1
+    assert np.all(faces[:, 0] != faces[:, 1]) and np.all(faces[:, 1] != faces[:, 2])
+
+
+@pytest.mark.parametrize("mode", ["plain", "color", "texture"])
+@pytest.mark.parametrize("ext", ["obj", "ply", "OBJ"])
+def test_output_mesh_files(tmp_path, mode, ext):
+    from PIL import Image
+    ctx = _ctx()
+    n = 48
+    d = _depth(n, seed=8)
+    src = tmp_path / "photo.png"
+    rgb = np.random.default_rng(2).integers(0, 256, size=(n, n, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(src)
+    dm = m.DepthMap(ctx, d, (n, n))
+    dest = tmp_path / f"mesh.{ext}"
+    vm = {"plain": m.VertexMode.Plain, "color": m.VertexMode.Color, "texture": m.VertexMode.Texture}[mode]
+    dm.output_image(str(dest), str(src), m.ImageOutputFormat.DepthMap(), vm)
+    od, _, _ = OO.clamp_minmax(d)
+    vi, nv, faces = OO.mesh_index(od)
+    uv, xyz = OO.mesh_vertices(od, vi, nv, (n, n))
+    colors = None
+    if mode == "color":      # source image is already n x n: the Lanczos resize is the identity
+        colors = np.zeros((nv, 3), np.uint8)
+        colors[vi[vi >= 0]] = rgb.reshape(-1, 3)[vi >= 0]
+    if ext.lower() == "obj":
+        assert dest.read_text() == OO.obj_text(uv, xyz, faces, mode, "mesh", colors)
+        mtl = tmp_path / "mesh.mtl"
+        if mode == "texture":
+            assert mtl.read_text() == OO.mtl_text(str(src))
+        else:
+            assert not mtl.exists()
+    else:
+        assert dest.read_bytes() == OO.ply_bytes(xyz, faces, mode, colors)
+
+
+def test_output_image_files(tmp_path):
+    from PIL import Image
+    ctx = _ctx()
+    n = 96
+    d = _depth(n, seed=4)
+    dm = m.DepthMap(ctx, d, (n, n))
+    od, mn, mx = OO.clamp_minmax(d)
+    dm.output_image(str(tmp_path / "d.png"), "unused", m.ImageOutputFormat.DepthMap(), m.VertexMode.Plain)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "d.png")), OO.depthmap_rgb(od, mn, mx))
+    noise = np.random.default_rng(0).integers(0, 256, size=(n, n, 3), dtype=np.uint8)
+    dm.output_image(str(tmp_path / "s.png"), "unused", m.ImageOutputFormat.Stereogram(None, 1 / 16), m.VertexMode.Plain,
+                    noise=noise)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "s.png")), OO.stereogram(od, mn, mx, n, n, 1 / 16, noise))
+
+
+def test_bad_destination_is_an_error(tmp_path):
+    import ctypes as C
+    ctx = _ctx()
+    d = _depth(16)
+    rc = ctx.lib.me_output_mesh(ctx.handle, C.c_void_p(d.ctypes.data), 16, 16, 16, 16,
+                                str(tmp_path / "x.txt").encode(), b"src", 0, None)
+    assert rc == 1
+    rc = ctx.lib.me_output_mesh(ctx.handle, C.c_void_p(d.ctypes.data), 16, 16, 16, 16,
+                                b"/nonexistent-dir/x.obj", b"src", 0, None)
+    assert rc == 7      # OutputError::Io
