@@ -101,6 +101,7 @@ void layernorm_typed(const float* x, const float* w, const float* b, void* y16, 
 }
 
 // ---------------------------------------------------------------------------------------
+#pragma clang fp contract(off)   // reconstruction.rs:116-124 reproduced operation for operation
 __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ img,
                                      int64_t pixels_per_image, int64_t total_pixels) {
     // reconstruction.rs:116-124: (x / 255 - 0.5) / 0.5 in f32, HWC -> CHW

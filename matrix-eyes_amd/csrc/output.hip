@@ -4,10 +4,14 @@
 // Bit-exactness: the reference is safe Rust, which never contracts a*b+c into an FMA and uses
 // IEEE division, round-half-away `f32::round` and saturating float->usize casts.
 // Every f32 operation below that feeds an index or a byte is therefore written with the
-// explicitly rounded intrinsics (__fmul_rn, __fadd_rn, __fsub_rn, __fdiv_rn), which the compiler
-// may not fuse whatever -ffp-contract says.
+// explicitly rounded intrinsics (__fmul_rn, __fadd_rn, __fsub_rn, __fdiv_rn) and the whole file is
+// compiled with floating-point contraction off.
 #include "common.h"
 #include "../../include/me_viridis_lut.h"
+
+// The rounded intrinsics are plain operators in the HIP headers, so contraction has to be switched
+// off for this translation unit as well (the Makefile also passes -ffp-contract=off).
+#pragma clang fp contract(off)
 
 namespace me {
 

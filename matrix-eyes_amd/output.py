@@ -34,12 +34,16 @@ class ImageOutputFormat:           # output.rs:27-31
 
 
 def _f32_round(x: float) -> int:
-    """f32::round (half away from zero) of an f32 value, as u32 (`as u32` saturates)."""
+    """f32::round (half away from zero, exact) of an f32 value, then `as u32` (saturating, NaN -> 0)."""
     x = np.float32(x)
-    r = np.floor(np.abs(x) + np.float32(0.5)) * np.sign(x) if np.isfinite(x) else x
-    if not np.isfinite(r) or r <= 0:
+    if not np.isfinite(x):
+        return 0 if (np.isnan(x) or x < 0) else 4294967295
+    t = np.trunc(x)
+    if abs(x - t) >= np.float32(0.5):      # x - trunc(x) is exact in f32
+        t += np.sign(x)
+    if t <= 0:
         return 0
-    return int(min(r, 4294967295.0))
+    return int(min(float(t), 4294967295.0))
 
 
 class DepthMap:
