@@ -1,6 +1,7 @@
 // Tile-configuration choice and (dtype, A-mode, epilogue) dispatch for the GEMM core.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gemm_core.h"
 
@@ -51,9 +52,10 @@ ProfScope::~ProfScope() {
     if (index >= 0) (void)hipEventRecord(profiler().entries[index].e1, stream);
 }
 
-static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w"};
-int gemm_num_configs() { return 4; }
-const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 4 ? kCfgNames[cfg] : "?"; }
+static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w",
+                                  "256x256x32/8w/ring4", "256x128x32/8w/ring4"};
+int gemm_num_configs() { return 6; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 6 ? kCfgNames[cfg] : "?"; }
 
 // 256 CUs; the large tiles run one workgroup per CU, so they want >= ~1.5 full rounds.
 static int pick_config(int64_t M, int64_t N) {
@@ -86,11 +88,15 @@ static void launch_typed(const GemmParams& p, AMode amode, EpiKind epi, int cfg,
     fail(ME_ERR_BAD_ARG, "gemm: unsupported (A-mode %d, epilogue %d)", (int)amode, (int)epi);
 }
 
-void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
+void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg) {
+    static const int dbg = getenv("ME_GEMM_DEBUG") ? atoi(getenv("ME_GEMM_DEBUG")) : 0;
+    GemmParams p = p_in;
+    p.debug = dbg;
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
              p.N, p.K);
     ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);
+    ME_CHECK(p.M < (1 << 30) && p.N < (1 << 30), ME_ERR_BAD_SHAPE, "gemm: %dx%d too large", p.M, p.N);
     ME_CHECK(p.N % 4 == 0, ME_ERR_BAD_SHAPE, "gemm: N=%d is not a multiple of 4", p.N);
     ME_CHECK(p.A && p.W, ME_ERR_BAD_ARG, "gemm: null operand");
     if (amode == A_CONV) {

@@ -70,6 +70,287 @@ __device__ __forceinline__ void store4_16(void* dst, float a, float b, float c, 
     *reinterpret_cast<v4*>(dst) = v;
 }
 
+// block -> tile.  Blocks b and b+8 share an XCD (and its 4 MiB L2), so each XCD gets a contiguous run
+// of the tile order; that order walks "super-rows" of 8 tile rows column by column, so the ~32 tiles
+// an XCD has in flight form an 8 x 4 patch: every A k-slab is shared by 4 of them and every W k-slab
+// by 8 (with the plain n-fastest order the whole W matrix streams through L2 once per tile row:
+// 44 % L2 misses on the fc1 shape, profiles/r01_pmc_gemm.md).
+template <int BM, int BN>
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+    constexpr int GM = 8;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);  // bijective
+    const int per_sr = GM * nbn;
+    const int sr = t / per_sr;
+    const int rem = t - sr * per_sr;
+    const int h = min(GM, nbm - sr * GM);  // rows of this super-row
+    const int n = rem / h;
+    const int rr = rem - n * h;
+    m0 = (sr * GM + rr) * BM;
+    n0 = n * BN;
+}
+
+// rows per epilogue pass (in 16-row m-tiles): the largest of {4, 2, 1} dividing MI whose LDS footprint
+// (all waves) fits in the main loop's allocation
+constexpr int epi_mi_chunk(int MI, int TN, int NW, int main_bytes) {
+    for (int c = 4; c >= 1; c >>= 1)
+        if (MI % c == 0 && NW * 16 * c * (TN * 4 + 16) <= main_bytes) return c;
+    return 1;
+}
+
+// Epilogue.  Each lane finishes one 8-column granule of one output row at a time: everything that
+// depends only on n (bias, gamma) is loaded once per lane, the pixel coordinates of bordered / pixel-
+// shuffled outputs walk with the row, f32 results leave as two 16-byte stores and 16-bit results as
+// ONE 16-byte store (8-byte stores ran the qkv epilogue at 2.9 TB/s, 16-byte ones at 7 TB/s).
+struct EpiLane {
+    float4 bias[2], gamma[2];  // per-lane constants for columns n..n+3 and n+4..n+7
+    int q, co;                 // EPI_CONVT: n = q * Cout + co
+};
+struct EpiRow {
+    int m;        // output row
+    int b, y, x;  // pixel of that row when rows are pixels of [B][out_H][out_W]
+};
+
+template <typename T>
+__device__ __forceinline__ void store_16bit(T* dst, const float (&a)[8], bool hi_ok) {
+    typedef T v8 __attribute__((ext_vector_type(8)));
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    if (hi_ok) {
+        v8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (T)a[e];
+        *reinterpret_cast<v8*>(dst) = v;
+    } else {
+        v4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)a[e];
+        *reinterpret_cast<v4*>(dst) = v;
+    }
+}
+
+// v: accumulators of columns n + 4*h .. n + 4*h + 3 (h = 0, 1); hi_ok: the second half exists (n + 4 < N)
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiRow& r, int n,
+                                                 const EpiLane& lc, const f32x4 (&v)[2], bool hi_ok) {
+    const int m = r.m;
+    float a[8];  // values for the 16-bit copy
+    if constexpr (EPI == EPI_STORE) {
+        const int64_t row32 = (int64_t)m * p.ldc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !hi_ok) break;
+            float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
+            float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
+            if (p.res32) {
+                const float4 r4 = *reinterpret_cast<const float4*>(p.res32 + row32 + n + 4 * h);
+                x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
+            }
+            if (p.res32b) {
+                const float4 r4 = *reinterpret_cast<const float4*>(p.res32b + row32 + n + 4 * h);
+                x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
+            }
+            float a0 = x0, a1 = x1, a2 = x2, a3 = x3;
+            if (p.act == ACT_GELU) {
+                a0 = gelu_erf(x0), a1 = gelu_erf(x1), a2 = gelu_erf(x2), a3 = gelu_erf(x3);
+            } else if (p.act == ACT_RELU) {
+                a0 = fmaxf(x0, 0.f), a1 = fmaxf(x1, 0.f), a2 = fmaxf(x2, 0.f), a3 = fmaxf(x3, 0.f);
+            }
+            if (p.out32)
+                *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
+                    p.act16_only ? make_float4(x0, x1, x2, x3) : make_float4(a0, a1, a2, a3);
+            a[4 * h] = a0, a[4 * h + 1] = a1, a[4 * h + 2] = a2, a[4 * h + 3] = a3;
+        }
+        if (p.out16) {
+            const int64_t row16 =
+                p.out16_border
+                    ? (((int64_t)r.b * (p.out_H + 2) + r.y + 1) * (p.out_W + 2) + r.x + 1) * p.ldc
+                    : row32;
+            store_16bit<T>((T*)p.out16 + row16 + n, a, hi_ok);
+        }
+    } else if constexpr (EPI == EPI_RESID_SCALE) {
+        const int64_t row32 = (int64_t)m * p.ldc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !hi_ok) break;
+            const float4 r4 = *reinterpret_cast<const float4*>(p.res32 + row32 + n + 4 * h);
+            // same operation order as the reference: (xs * gamma) + residual
+            *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
+                make_float4((v[h][0] + lc.bias[h].x) * lc.gamma[h].x + r4.x,
+                            (v[h][1] + lc.bias[h].y) * lc.gamma[h].y + r4.y,
+                            (v[h][2] + lc.bias[h].z) * lc.gamma[h].z + r4.z,
+                            (v[h][3] + lc.bias[h].w) * lc.gamma[h].w + r4.w);
+        }
+    } else if constexpr (EPI == EPI_PATCH_EMBED) {
+        const int w = m / p.tokens_per_window;
+        const int patch = m - w * p.tokens_per_window;
+        const int64_t row32 = ((int64_t)w * (p.tokens_per_window + 1) + 1 + patch) * p.ldc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !hi_ok) break;
+            const float4 e4 =
+                *reinterpret_cast<const float4*>(p.pos + (int64_t)(1 + patch) * p.N + n + 4 * h);
+            *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
+                make_float4(v[h][0] + lc.bias[h].x + e4.x, v[h][1] + lc.bias[h].y + e4.y,
+                            v[h][2] + lc.bias[h].z + e4.z, v[h][3] + lc.bias[h].w + e4.w);
+        }
+    } else if constexpr (EPI == EPI_CONVT) {
+        const int oy = 2 * r.y + (lc.q >> 1), ox = 2 * r.x + (lc.q & 1);
+        const int oH = 2 * p.out_H, oW = 2 * p.out_W;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !hi_ok) break;
+            const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
+            const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
+            if (p.out32) {
+                const int64_t o = (((int64_t)r.b * oH + oy) * oW + ox) * p.ldc + lc.co + 4 * h;
+                *reinterpret_cast<float4*>(p.out32 + o) = make_float4(x0, x1, x2, x3);
+            }
+            const bool relu = p.act == ACT_RELU;
+            a[4 * h] = relu ? fmaxf(x0, 0.f) : x0, a[4 * h + 1] = relu ? fmaxf(x1, 0.f) : x1;
+            a[4 * h + 2] = relu ? fmaxf(x2, 0.f) : x2, a[4 * h + 3] = relu ? fmaxf(x3, 0.f) : x3;
+        }
+        if (p.out16) {
+            const int64_t o =
+                p.out16_border
+                    ? ((((int64_t)r.b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) * p.ldc + lc.co)
+                    : ((((int64_t)r.b * oH + oy) * oW + ox) * p.ldc + lc.co);
+            store_16bit<T>((T*)p.out16 + o, a, hi_ok);
+        }
+    }
+}
+
+// acc[i][j] is the 16x16 tile (m-tile i, n-tile j) of this wave's TM x TN block: lane holds row
+// m = ... + (lane & 15), columns n = ... + 4*(lane >> 4) + r.  Each wave transposes its block through a
+// private LDS region (the main loop's LDS is free by now) so that 8 consecutive lanes own one whole
+// TN-column row segment.
+template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
+                                              int wm, int wn, int lane, char* epi_lds) {
+    const int frow = lane & 15;
+    const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
+    if constexpr (EPI == EPI_HEAD_FINAL) {
+        // N <= 32 = the whole tile width (WN == 1): relu(acc + bias) . w2, reduced over n.
+        float w2v[NI][4], bv[NI][4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = j * 16 + ncol + r;
+                const bool ok = n < p.N;
+                w2v[j][r] = ok ? p.w2[n] : 0.f;
+                bv[j][r] = ok ? p.bias[n] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += fmaxf(acc[i][j][r] + bv[j][r], 0.f) * w2v[j][r];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const int m = m0 + wm * TM + i * 16 + frow;
+            if (lane < 16 && m < p.M) {
+                float v = fmaxf(s + p.b2[0], 0.f);
+                if (p.f_norm) v = v / p.f_norm[m / p.pixels_per_image];
+                v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
+                p.out32[m] = v;
+            }
+        }
+    } else {
+        constexpr int RS = TN * 4 + 16;  // padded LDS row stride, bytes
+        constexpr int ROWS = 16 * MI_CH;  // rows per pass
+        constexpr int GPR = TN / 8;       // 8-column granules per row
+        constexpr int RPI = 64 / GPR;     // rows covered by one wave-instruction
+        constexpr int ITERS = ROWS / RPI;
+        static_assert(MI % MI_CH == 0 && 64 % GPR == 0 && ROWS % RPI == 0, "epilogue pass shape");
+        const int gc = lane % GPR, r0 = lane / GPR;
+        const int n = n0 + wn * TN + gc * 8;
+        const bool n_ok = n < p.N, hi_ok = n + 4 < p.N;
+        EpiLane lc;
+        lc.bias[0] = lc.bias[1] = lc.gamma[0] = lc.gamma[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lc.q = 0, lc.co = n;
+        if constexpr (EPI == EPI_CONVT) {
+            lc.q = n / p.Cout;
+            lc.co = n - lc.q * p.Cout;
+        }
+        if (n_ok) {
+            if (p.bias) {
+                lc.bias[0] = *reinterpret_cast<const float4*>(p.bias + lc.co);
+                if (hi_ok) lc.bias[1] = *reinterpret_cast<const float4*>(p.bias + lc.co + 4);
+            }
+            if constexpr (EPI == EPI_RESID_SCALE) {
+                lc.gamma[0] = *reinterpret_cast<const float4*>(p.gamma + n);
+                if (hi_ok) lc.gamma[1] = *reinterpret_cast<const float4*>(p.gamma + n + 4);
+            }
+        }
+        EpiRow row;
+        row.m = m0 + wm * TM + r0;
+        row.b = row.y = row.x = 0;
+        const bool pix = EPI == EPI_CONVT || (EPI == EPI_STORE && p.out16_border);
+        if (pix) {  // one pair of divisions per lane; afterwards the pixel walks with the row
+            const int ppi = p.out_H * p.out_W;
+            const int mm = row.m < p.M ? row.m : p.M - 1;
+            row.b = mm / ppi;
+            const int rem = mm - row.b * ppi;
+            row.y = rem / p.out_W;
+            row.x = rem - row.y * p.out_W;
+        }
+#pragma unroll
+        for (int pass = 0; pass < MI / MI_CH; ++pass) {
+#pragma unroll
+            for (int i = 0; i < MI_CH; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    *reinterpret_cast<f32x4*>(epi_lds + (i * 16 + frow) * RS + (j * 16 + ncol) * 4) =
+                        acc[pass * MI_CH + i][j];
+            // LDS operations of one wave execute in order: the reads below see the writes above
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const char* src = epi_lds + (it * RPI + r0) * RS + gc * 32;
+                f32x4 v[2];
+                v[0] = *reinterpret_cast<const f32x4*>(src);
+                v[1] = *reinterpret_cast<const f32x4*>(src + 16);
+                if (row.m < p.M && n_ok) epilogue_granule<T, EPI>(p, row, n, lc, v, hi_ok);
+                row.m += RPI;
+                if (pix) {
+                    row.x += RPI;
+                    while (row.x >= p.out_W) {
+                        row.x -= p.out_W;
+                        if (++row.y == p.out_H) row.y = 0, ++row.b;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// sched_group_barrier wants literal counts: compile-time recursion over the fragment groups
+template <int G, int NI, int g>
+struct SchedPin {
+    static __device__ __forceinline__ void run() {
+        constexpr int reads = (g + 2 < G ? 1 : 0) + (g < NI ? 1 : 0);
+        if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x8, NI, 0);                                // MFMA
+        SchedPin<G, NI, g + 1>::run();
+    }
+    // ring kernel: one A read per group (none for the last two), NM MFMAs per group
+    template <int NM>
+    static __device__ __forceinline__ void run_n() {
+        if constexpr (g + 2 < G) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, NM, 0);
+        SchedPin<G, NI, g + 1>::template run_n<NM>();
+    }
+};
+template <int G, int NI>
+struct SchedPin<G, NI, G> {
+    static __device__ __forceinline__ void run() {}
+    template <int NM>
+    static __device__ __forceinline__ void run_n() {}
+};
+
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -89,17 +370,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- block -> tile, XCD-aware (blocks b and b+8 share an XCD's L2; give each XCD a
-    // contiguous run of tiles, n fastest, so the A panel of a tile row is reused from L2) ----
-    const int nbn = (p.N + BN - 1) / BN;
-    int wgid;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (wgid / nbn) * BM;
-    const int n0 = (wgid % nbn) * BN;
+    int m0, n0;
+    tile_origin<BM, BN>(p, m0, n0);
 
     // ---- per-lane source pointers for the staging loads ----
     const int srow = lane >> 3;  // row within an 8-row LDS-DMA piece
@@ -177,176 +449,234 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int a_rd = (wm * TM + frow) * 128;
     const int b_rd = A_BYTES + (wn * TN + frow) * 128;
 
-    stage(0, 0);
+    if (p.debug < 5) stage(0, 0);
     __syncthreads();
+    if (p.debug == 6) return;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    if (p.debug == 4) {  // development: MFMA issue floor
+        frag a0 = *reinterpret_cast<const frag*>(smem + a_rd + fslot0);
+        frag w0 = *reinterpret_cast<const frag*>(smem + b_rd + fslot0);
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = MfmaOp<T>::run(w0, a0, acc[i][j]);
+            asm volatile("" : "+v"(a0), "+v"(w0));
+        }
+    }
+    for (int kt = 0; kt < nk && p.debug < 3; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < nk && p.debug != 2) stage(kt + 1, buf ^ 1);
         const char* sb = smem + buf * STAGE_BYTES;
+        if (p.debug != 1) {
+            // Software-pipelined fragment feed.  The 2*MI "groups" (k-substep kk, m-tile i) each
+            // issue NI MFMAs on one A fragment; the A fragment of group g+2 and (early on) the W
+            // fragments of the second k-substep are read from LDS while group g's MFMAs run, so after
+            // the first two groups no MFMA waits for an LDS round trip.
+            constexpr int G = 2 * MI;
+            frag af[G], wf[2][NI];
+            auto rd_a = [&](int g) {
+                return *reinterpret_cast<const frag*>(sb + a_rd + (g % MI) * 2048 +
+                                                      (g < MI ? fslot0 : fslot1));
+            };
+            auto rd_w = [&](int kk, int j) {
+                return *reinterpret_cast<const frag*>(sb + b_rd + j * 2048 + (kk == 0 ? fslot0 : fslot1));
+            };
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int slot = kk == 0 ? fslot0 : fslot1;
-            frag af[MI], wf[NI];
+            for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
+            af[0] = rd_a(0);
+            if (G > 1) af[1] = rd_a(1);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const frag*>(sb + a_rd + i * 2048 + slot);
+            for (int g = 0; g < G; ++g) {
+                if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+                if (g < NI) wf[1][g] = rd_w(1, g);
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                wf[j] = *reinterpret_cast<const frag*>(sb + b_rd + j * 2048 + slot);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = MfmaOp<T>::run(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < NI; ++j)
+                    acc[g % MI][j] = MfmaOp<T>::run(wf[g < MI ? 0 : 1][j], af[g], acc[g % MI][j]);
+            }
+            // pin that order: (reads of the group, then its NI MFMAs) x G
+            __builtin_amdgcn_sched_group_barrier(0x100, NI + (G > 1 ? 2 : 1), 0);
+            SchedPin<G, NI, 0>::run();
         }
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ epilogue
-    const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
-    if constexpr (EPI == EPI_HEAD_FINAL) {
-        // N <= 32 = the whole tile width (WN == 1): relu(acc + bias) . w2, reduced over n.
-        float w2v[NI][4], bv[NI][4];
+    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, 2 * STAGE_BYTES);
+    gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(p, acc, m0, n0, wm, wn, lane,
+                                                 smem + wave * (16 * MI_CH * (TN * 4 + 16)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring main loop: 32-deep K slabs in an NS-slot LDS ring, LDS-DMA running NS-1 slabs ahead of the
+// MFMAs, ONE raw s_barrier per slab and a counted `s_waitcnt vmcnt(N)` that leaves the younger slabs
+// in flight across the barrier (cdna_hip_programming.md §5 "Pipelining across barriers", T3/T4).
+// LDS rows are 64 bytes (4 chunks of 16 B); chunk c of row r sits at slot c ^ ((-(r >> 2)) & 3), which
+// spreads every ds_read_b128 lane group over all 16 slots of the 256-byte bank row.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+    // one statement: the wait retires this wave's share of the slab, the barrier publishes everyone's
+    // and frees the slot the next LDS-DMA overwrites; "memory" keeps LDS accesses on their side
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int AMODE, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_ITERS = (BM / 16) / NW, B_ITERS = (BN / 16) / NW;  // 1 KiB piece = 16 rows x 64 B
+    constexpr int PER_STAGE = A_ITERS + B_ITERS;                       // LDS-DMA instructions per wave
+    static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile rows must split over waves");
+    static_assert(NS >= 3 && (NS - 2) * PER_STAGE <= 63, "ring depth");
+    typedef typename MfmaOp<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int m0, n0;
+    tile_origin<BM, BN>(p, m0, n0);
+
+    // staging: lane -> row (lane >> 2) of a 16-row piece, slot lane & 3
+    const int srow = lane >> 2, sslot = lane & 3;
+    const int schunk = sslot ^ ((4 - (lane >> 4)) & 3);  // piece bases are multiples of 16 rows
+    const char* a_src[A_ITERS];
+    const char* w_src[B_ITERS];
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = j * 16 + ncol + r;
-                const bool ok = n < p.N;
-                w2v[j][r] = ok ? p.w2[n] : 0.f;
-                bv[j][r] = ok ? p.bias[n] : 0.f;
-            }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s += fmaxf(acc[i][j][r] + bv[j][r], 0.f) * w2v[j][r];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const int m = m0 + wm * TM + i * 16 + frow;
-            if (lane < 16 && m < p.M) {
-                float v = fmaxf(s + p.b2[0], 0.f);
-                if (p.f_norm) v = v / p.f_norm[m / p.pixels_per_image];
-                v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
-                p.out32[m] = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * TM + i * 16 + frow;
-            if (m >= p.M) continue;
-            int64_t row32 = 0, row16 = 0;  // element offsets of this output row
-            [[maybe_unused]] int pe_patch = 0;
-            [[maybe_unused]] int ct_b = 0, ct_y = 0, ct_x = 0;
-            if constexpr (EPI == EPI_RESID_SCALE) {
-                row32 = (int64_t)m * p.ldc;
-                row16 = row32;
-            } else if constexpr (EPI == EPI_STORE) {
-                row32 = (int64_t)m * p.ldc;
-                if (p.out16_border) {  // rows are pixels of [B][out_H][out_W]
-                    const int ppi = p.out_H * p.out_W;
-                    const int b = m / ppi;
-                    const int rem = m - b * ppi;
-                    const int y = rem / p.out_W;
-                    const int x = rem - y * p.out_W;
-                    row16 = (((int64_t)b * (p.out_H + 2) + y + 1) * (p.out_W + 2) + x + 1) * p.ldc;
-                } else {
-                    row16 = row32;
-                }
-            } else if constexpr (EPI == EPI_PATCH_EMBED) {
-                const int w = m / p.tokens_per_window;
-                pe_patch = m - w * p.tokens_per_window;
-                row32 = ((int64_t)w * (p.tokens_per_window + 1) + 1 + pe_patch) * p.ldc;
-            } else if constexpr (EPI == EPI_CONVT) {
-                const int ppi = p.out_H * p.out_W;  // input pixels per image
-                ct_b = m / ppi;
-                const int rem = m - ct_b * ppi;
-                ct_y = rem / p.out_W;
-                ct_x = rem - ct_y * p.out_W;
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * TN + j * 16 + ncol;
-                if (n >= p.N) continue;
-                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-                if constexpr (EPI == EPI_STORE) {
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                        v0 += b4.x, v1 += b4.y, v2 += b4.z, v3 += b4.w;
-                    }
-                    if (p.res32) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.res32 + row32 + n);
-                        v0 += r4.x, v1 += r4.y, v2 += r4.z, v3 += r4.w;
-                    }
-                    if (p.res32b) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.res32b + row32 + n);
-                        v0 += r4.x, v1 += r4.y, v2 += r4.z, v3 += r4.w;
-                    }
-                    float a0 = v0, a1 = v1, a2 = v2, a3 = v3;
-                    if (p.act == ACT_GELU) {
-                        a0 = gelu_erf(v0), a1 = gelu_erf(v1), a2 = gelu_erf(v2), a3 = gelu_erf(v3);
-                    } else if (p.act == ACT_RELU) {
-                        a0 = fmaxf(v0, 0.f), a1 = fmaxf(v1, 0.f), a2 = fmaxf(v2, 0.f),
-                        a3 = fmaxf(v3, 0.f);
-                    }
-                    if (p.out32) {
-                        if (p.act16_only)
-                            *reinterpret_cast<float4*>(p.out32 + row32 + n) =
-                                make_float4(v0, v1, v2, v3);
-                        else
-                            *reinterpret_cast<float4*>(p.out32 + row32 + n) =
-                                make_float4(a0, a1, a2, a3);
-                    }
-                    if (p.out16) store4_16<T>((T*)p.out16 + row16 + n, a0, a1, a2, a3);
-                } else if constexpr (EPI == EPI_RESID_SCALE) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                    const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + n);
-                    const float4 r4 = *reinterpret_cast<const float4*>(p.res32 + row32 + n);
-                    // same operation order as the reference: (xs * gamma) + residual
-                    v0 = (v0 + b4.x) * g4.x + r4.x;
-                    v1 = (v1 + b4.y) * g4.y + r4.y;
-                    v2 = (v2 + b4.z) * g4.z + r4.z;
-                    v3 = (v3 + b4.w) * g4.w + r4.w;
-                    *reinterpret_cast<float4*>(p.out32 + row32 + n) = make_float4(v0, v1, v2, v3);
-                } else if constexpr (EPI == EPI_PATCH_EMBED) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                    const float4 e4 = *reinterpret_cast<const float4*>(
-                        p.pos + (int64_t)(1 + pe_patch) * p.N + n);
-                    *reinterpret_cast<float4*>(p.out32 + row32 + n) =
-                        make_float4(v0 + b4.x + e4.x, v1 + b4.y + e4.y, v2 + b4.z + e4.z,
-                                    v3 + b4.w + e4.w);
-                } else if constexpr (EPI == EPI_CONVT) {
-                    const int q = n / p.Cout;
-                    const int co = n - q * p.Cout;
-                    const int oy = 2 * ct_y + (q >> 1), ox = 2 * ct_x + (q & 1);
-                    const int oH = 2 * p.out_H, oW = 2 * p.out_W;
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
-                        v0 += b4.x, v1 += b4.y, v2 += b4.z, v3 += b4.w;
-                    }
-                    if (p.out32) {
-                        const int64_t o = (((int64_t)ct_b * oH + oy) * oW + ox) * p.ldc + co;
-                        *reinterpret_cast<float4*>(p.out32 + o) = make_float4(v0, v1, v2, v3);
-                    }
-                    if (p.out16) {
-                        float a0 = v0, a1 = v1, a2 = v2, a3 = v3;
-                        if (p.act == ACT_RELU)
-                            a0 = fmaxf(v0, 0.f), a1 = fmaxf(v1, 0.f), a2 = fmaxf(v2, 0.f),
-                            a3 = fmaxf(v3, 0.f);
-                        const int64_t o =
-                            p.out16_border
-                                ? ((((int64_t)ct_b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) *
-                                       p.ldc + co)
-                                : ((((int64_t)ct_b * oH + oy) * oW + ox) * p.ldc + co);
-                        store4_16<T>((T*)p.out16 + o, a0, a1, a2, a3);
-                    }
-                }
-            }
+    for (int i = 0; i < A_ITERS; ++i) {
+        int gm = m0 + (i * NW + wave) * 16 + srow;
+        gm = gm < p.M ? gm : p.M - 1;
+        if constexpr (AMODE == A_PLAIN) {
+            a_src[i] = (const char*)p.A + ((int64_t)gm * p.lda) * 2 + schunk * 16;
+        } else {
+            const int ppi = p.out_H * p.out_W;
+            const int b = gm / ppi;
+            const int rem = gm - b * ppi;
+            const int y = rem / p.out_W;
+            const int x = rem - y * p.out_W;
+            const int64_t pix = ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
+            a_src[i] = (const char*)p.A + pix * p.Cin * 2 + schunk * 16;
         }
     }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        int gn = n0 + (i * NW + wave) * 16 + srow;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_src[i] = (const char*)p.W + ((int64_t)gn * p.K) * 2 + schunk * 16;
+    }
+
+    const int ns = p.K / 32;
+    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 32 : 1;
+    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
+    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
+
+    auto stage = [&](int s, int slot) {
+        char* la = smem + slot * STAGE_BYTES;
+        char* lb = la + A_BYTES;
+        int64_t a_koff;
+        if constexpr (AMODE == A_PLAIN) {
+            a_koff = (int64_t)s * 64;
+        } else {
+            a_koff = ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 +
+                     tap_kc * 64;
+            if (++tap_kc == cin_steps) {
+                tap_kc = 0;
+                if (++tap_kx == p.KW) {
+                    tap_kx = 0;
+                    ++tap_ky;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) glds16(a_src[i] + a_koff, la + (i * NW + wave) * 1024);
+        const int64_t w_koff = (int64_t)s * 64;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) glds16(w_src[i] + w_koff, lb + (i * NW + wave) * 1024);
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fslot = ((lane >> 4) ^ ((4 - (frow >> 2)) & 3)) * 16;
+    const int a_rd = (wm * TM + frow) * 64 + fslot;
+    const int b_rd = A_BYTES + (wn * TN + frow) * 64 + fslot;
+
+    // prologue: NS-1 slabs in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < ns) stage(s, s);
+
+    int slot = 0;
+    for (int s = 0; s < ns; ++s) {
+        // slabs younger than s that may stay in flight: min(NS-2, ns-1-s)
+        const int younger = ns - 1 - s;
+        if (younger >= NS - 2)
+            wait_vmcnt_barrier<(NS - 2) * PER_STAGE>();
+        else if (NS > 3 && younger == 1)
+            wait_vmcnt_barrier<PER_STAGE>();
+        else
+            wait_vmcnt_barrier<0>();
+        static_assert(NS <= 4, "tail wait ladder written for NS <= 4");
+        if (s + NS - 1 < ns && p.debug != 2) {
+            int ps = slot + NS - 1;
+            ps = ps >= NS ? ps - NS : ps;
+            stage(s + NS - 1, ps);
+        }
+        const char* sb = smem + slot * STAGE_BYTES;
+        if (p.debug == 1) {
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            continue;
+        }
+        {
+            // same software-pipelined fragment feed as the 2-stage kernel (one k-substep per slab)
+            frag af[MI], wf[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const frag*>(sb + b_rd + j * 1024);
+            af[0] = *reinterpret_cast<const frag*>(sb + a_rd);
+            if (MI > 1) af[1] = *reinterpret_cast<const frag*>(sb + a_rd + 1024);
+#pragma unroll
+            for (int g = 0; g < MI; ++g) {
+                if (g + 2 < MI) af[g + 2] = *reinterpret_cast<const frag*>(sb + a_rd + (g + 2) * 1024);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[g][j] = MfmaOp<T>::run(wf[j], af[g], acc[g][j]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NI + (MI > 1 ? 2 : 1), 0);
+            SchedPin<MI, 0, 0>::template run_n<NI>();
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    __syncthreads();  // every wave is done with the ring before it becomes epilogue scratch
+    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, NS * STAGE_BYTES);
+    gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(p, acc, m0, n0, wm, wn, lane,
+                                                 smem + wave * (16 * MI_CH * (TN * 4 + 16)));
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int AMODE, int EPI>
+void gemm_launch_ring(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = NS * (BM + BN) * 64;
+    auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, NS, AMODE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   smem));
+        attr_set = true;
+    }
+    const int64_t grid = cdiv(p.M, BM) * cdiv(p.N, BN);
+    ME_CHECK(grid > 0 && grid < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
+             (long long)grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
+    ME_HIP(hipGetLastError());
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
@@ -379,6 +709,8 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 1: gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 256, 128, 4, 2, AMODE, EPI>(p, stream); break;     \
+            case 4: gemm_launch_ring<T, 256, 256, 2, 4, 4, AMODE, EPI>(p, stream); break; \
+            case 5: gemm_launch_ring<T, 256, 128, 4, 2, 4, AMODE, EPI>(p, stream); break; \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

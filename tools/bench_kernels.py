@@ -47,7 +47,7 @@ def main():
             out16 = torch.empty(Mx, N, dtype=t16, device="cuda")
             x32 = torch.randn(Mx, N, device="cuda")
             gamma = torch.rand(N, device="cuda")
-            for cfg in range(4):
+            for cfg in range(lib.me_op_gemm_config_count()):
                 if name in ("proj", "fc2"):
                     f = lambda: lib.me_op_linear_residual(h, Mx, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x32), cfg)
                 else:
@@ -81,7 +81,7 @@ def main():
         out16 = torch.zeros(1, Hh + 2, Hh + 2, 256, dtype=t16, device="cuda")
         r32 = torch.randn(Hh * Hh, 256, device="cuda")
         o32 = torch.empty(Hh * Hh, 256, device="cuda")
-        for cfg in range(4):
+        for cfg in range(lib.me_op_gemm_config_count()):
             ms = timeit(lambda: lib.me_op_conv2d(h, ptr(xb), 1, Hh, Hh, 256, ptr(w), 256, 3, 1, ptr(bias), ptr(r32), None, ptr(o32), ptr(out16), 1, 2, 0, cfg), iters=5)
             fl = 2.0 * Hh * Hh * 2304 * 256
             res.append(dict(op="conv3x3", H=Hh, cfg=lib.me_op_gemm_config_name(cfg).decode(), ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))

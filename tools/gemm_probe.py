@@ -1,0 +1,60 @@
+"""Runs ONE kernel shape repeatedly so that rocprofv3 --pmc / --kernel-trace can be pointed at it.
+usage: gemm_probe.py <op> <cfg> [iters]   op in qkv|proj|fc1|fc2|conv768|attn"""
+import ctypes as C
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import matrix_eyes_amd as m
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def main():
+    op, cfg = sys.argv[1], int(sys.argv[2])
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    ctx = m.Context(0, "f16", m.ModelConfig.tiny())
+    lib, h = ctx.lib, ctx.handle
+    t16 = torch.float16
+    M = 35 * 577
+    shapes = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
+    if op in shapes:
+        N, K = shapes[op]
+        a = torch.randn(M, K, device="cuda").to(t16)
+        w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(t16)
+        bias = torch.randn(N, device="cuda")
+        out16 = torch.empty(M, N, dtype=t16, device="cuda")
+        x32 = torch.randn(M, N, device="cuda")
+        gamma = torch.rand(N, device="cuda")
+        if op in ("proj", "fc2"):
+            f = lambda: lib.me_op_linear_residual(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x32), cfg)
+        else:
+            f = lambda: lib.me_op_linear(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(out16), None, 1 if op == "fc1" else 0, cfg)
+    elif op == "conv768":
+        Hh = 768
+        xb = torch.randn(1, Hh + 2, Hh + 2, 256, device="cuda").to(t16)
+        w = (torch.randn(256, 9 * 256, device="cuda") / 48).to(t16)
+        bias = torch.randn(256, device="cuda")
+        out16 = torch.zeros(1, Hh + 2, Hh + 2, 256, dtype=t16, device="cuda")
+        r32 = torch.randn(Hh * Hh, 256, device="cuda")
+        o32 = torch.empty(Hh * Hh, 256, device="cuda")
+        f = lambda: lib.me_op_conv2d(h, ptr(xb), 1, Hh, Hh, 256, ptr(w), 256, 3, 1, ptr(bias), ptr(r32), None, ptr(o32), ptr(out16), 1, 2, 0, cfg)
+    elif op == "attn":
+        qkv = torch.randn(M, 3072, device="cuda").to(t16)
+        out = torch.empty(M, 1024, dtype=t16, device="cuda")
+        f = lambda: lib.me_op_attention(h, ptr(qkv), ptr(out), 35, 577, 16)
+    else:
+        raise SystemExit("unknown op")
+    for _ in range(iters):
+        rc = f()
+        assert rc == 0, rc
+    ctx.synchronize()
+
+
+if __name__ == "__main__":
+    main()
