@@ -133,6 +133,11 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
+        for (int i = 0; i < 2; ++i)
+            ME_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+        ME_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ME_HIP(hipEventCreateWithFlags(&ctx->ev_img, hipEventDisableTiming));
+        ME_HIP(hipEventCreateWithFlags(&ctx->ev_fov, hipEventDisableTiming));
         build_weight_table(ctx);
         ME_HIP(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
         resolve_weights(ctx);
@@ -153,6 +158,13 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->side[i]) {
+            (void)hipStreamSynchronize(ctx->side[i]);
+            (void)hipStreamDestroy(ctx->side[i]);
+        }
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_img, ctx->ev_fov})
+        if (e) (void)hipEventDestroy(e);
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -294,7 +306,7 @@ int32_t me_encoder_forward_encodings(me_ctx* ctx, const float* x, int32_t batch,
     const me_model_config& c = ctx->cfg;
     const int S = ctx->S(), g = ctx->g();
     const float* x_dev = (const float*)to_device(ctx, x, (size_t)batch * 3 * S * S * 4, "io.img");
-    stage_encoder(ctx, x_dev, batch);
+    stage_encoder(ctx, x_dev, batch, false);
     const int H[5] = {32 * g, 16 * g, 8 * g, 4 * g, 2 * g};
     const int Cc[5] = {c.dec_dim, c.enc_dims[0], c.enc_dims[1], c.enc_dims[2], c.enc_dims[3]};
     const char* names[5] = {"enc0.f32", "enc1.16b", "enc2.16b", "enc3.16b", "enc4.16b"};
@@ -378,7 +390,8 @@ int32_t me_fov_forward(me_ctx* ctx, const float* x, const float* lowres_feature,
     float* low32 = (float*)site_buf(ctx, "lowres.f32", nl * 4);
     nchw32_to_nhwc_launch(low, low32, nullptr, batch, 2 * g, 2 * g, dec, 0, 0, ctx->dtype, ctx->stream);
     OutBuf o = out_buf(ctx, fov_deg, (size_t)batch * 4, "fov_deg");
-    stage_fov(ctx, batch, (float*)o.dev);
+    stage_fov_vit(ctx, batch, ctx->stream);
+    stage_fov_tail(ctx, batch, (float*)o.dev, false);
     finish(ctx, o);
     ME_API_END(ctx)
 }
@@ -387,7 +400,7 @@ namespace {
 void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const float* f_norm,
                         float* inverse_depth, float* fov_deg_out) {
     const int S = ctx->S();
-    stage_encoder(ctx, img_dev, batch);
+    stage_encoder(ctx, img_dev, batch, f_norm == nullptr);
     stage_decoder(ctx, batch, false);
     float* fnorm_dev = (float*)site_buf(ctx, "f_norm", (size_t)batch * 4);
     OutBuf ofov;
@@ -401,7 +414,7 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     } else {
         // mod.rs:343-358
         ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
-        stage_fov(ctx, batch, (float*)ofov.dev);
+        stage_fov_tail(ctx, batch, (float*)ofov.dev, true);
     }
     OutBuf o = out_buf(ctx, inverse_depth, (size_t)batch * S * S * 4, "io.depth");
     stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev);
@@ -531,10 +544,17 @@ int32_t me_mesh_vertices(me_ctx* ctx, const float* depth, int32_t width, int32_t
 }
 
 // ---- kernel-level surface (matrix_eyes_hip_ops.h) -------------------------------------------
+static unsigned long long* g_stamps = nullptr;  // diagnostic builds (-DME_GEMM_STAMPS) only
+extern "C" int32_t me_debug_set_stamps(void* dev_ptr) {
+    g_stamps = (unsigned long long*)dev_ptr;
+    return ME_OK;
+}
+
 int32_t me_op_linear(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, const void* W16,
                      const float* bias, void* out16, float* out32, int32_t act, int32_t tile_cfg) {
     ME_API_BEGIN(ctx)
     GemmParams p = GemmParams();
+    p.stamps = g_stamps;
     p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16, p.bias = bias;
     p.out16 = out16, p.out32 = out32, p.ldc = N, p.act = act;
     gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, ctx->stream, tile_cfg);

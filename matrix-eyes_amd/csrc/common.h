@@ -123,7 +123,8 @@ struct GemmParams {
     const float* f_norm;   // device [B] (one per image) or null (= 1): out32[m] = clamp(v / f_norm[b])
     float clamp_lo, clamp_hi;  // mod.rs:362 clamp(1e-4, 1e4); +-inf for the canonical head output
     int32_t pixels_per_image;
-    int32_t debug;  // development only (env ME_GEMM_DEBUG): 1 = staging loads only, 2 = MFMA/LDS reads only
+    // diagnostic builds only (tools/gemm_stamps.py): per-workgroup s_memrealtime stamps, or null
+    unsigned long long* stamps;
 };
 
 // dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).

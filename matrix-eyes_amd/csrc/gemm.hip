@@ -52,19 +52,19 @@ ProfScope::~ProfScope() {
     if (index >= 0) (void)hipEventRecord(profiler().entries[index].e1, stream);
 }
 
-static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w",
-                                  "256x256x32/8w/ring4", "256x128x32/8w/ring4"};
-int gemm_num_configs() { return 6; }
-const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 6 ? kCfgNames[cfg] : "?"; }
+static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w"};
+int gemm_num_configs() { return 4; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 4 ? kCfgNames[cfg] : "?"; }
 
-// 256 CUs; the large tiles run one workgroup per CU, so they want >= ~1.5 full rounds.
+// Measured on MI355X (profiles/r01_kernel_microbench_f16.json): the 256x256 tile wins when there are
+// >= ~1.5 rounds of 256 workgroups and N is wide (qkv, fc1); the 128x128 tile (two workgroups per CU,
+// so one's epilogue overlaps the other's MFMAs) wins for N <= 1024 (proj, fc2, the 256-channel
+// convolutions); the 64x64 tile is for the single-window ViTs and the low-resolution decoder levels.
 static int pick_config(int64_t M, int64_t N) {
     const int64_t t0 = cdiv(M, 256) * cdiv(N, 256);
-    if (N >= 256 && t0 >= 400) return 0;
-    const int64_t t3 = cdiv(M, 256) * cdiv(N, 128);
-    if (N >= 128 && t3 >= 300) return 3;
+    if (N >= 2048 && t0 >= 400) return 0;
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
-    if (N >= 128 && t1 >= 128) return 1;
+    if (N >= 128 && t1 >= 256) return 1;
     return 2;
 }
 
@@ -88,11 +88,8 @@ static void launch_typed(const GemmParams& p, AMode amode, EpiKind epi, int cfg,
     fail(ME_ERR_BAD_ARG, "gemm: unsupported (A-mode %d, epilogue %d)", (int)amode, (int)epi);
 }
 
-void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
+void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg) {
-    static const int dbg = getenv("ME_GEMM_DEBUG") ? atoi(getenv("ME_GEMM_DEBUG")) : 0;
-    GemmParams p = p_in;
-    p.debug = dbg;
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
              p.N, p.K);
     ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);

@@ -47,7 +47,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // tail keeps its relative accuracy.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp), not the
+                                                                    // 10-instruction IEEE division
     float poly = 1.061405429f;
     poly = poly * t - 1.453152027f;
     poly = poly * t + 1.421413741f;
@@ -76,10 +77,9 @@ __device__ __forceinline__ void store4_16(void* dst, float a, float b, float c, 
 // by 8 (with the plain n-fastest order the whole W matrix streams through L2 once per tile row:
 // 44 % L2 misses on the fc1 shape, profiles/r01_pmc_gemm.md).
 template <int BM, int BN>
-__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0) {
     constexpr int GM = 8;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);  // bijective
     const int per_sr = GM * nbn;
@@ -330,27 +330,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // sched_group_barrier wants literal counts: compile-time recursion over the fragment groups
 template <int G, int NI, int g>
 struct SchedPin {
+    // NV > 0 additionally asks for NV VMEM reads spread over the groups (unused: measured slower)
+    template <int NV>
     static __device__ __forceinline__ void run() {
         constexpr int reads = (g + 2 < G ? 1 : 0) + (g < NI ? 1 : 0);
         if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);  // DS read
         __builtin_amdgcn_sched_group_barrier(0x8, NI, 0);                                // MFMA
-        SchedPin<G, NI, g + 1>::run();
-    }
-    // ring kernel: one A read per group (none for the last two), NM MFMAs per group
-    template <int NM>
-    static __device__ __forceinline__ void run_n() {
-        if constexpr (g + 2 < G) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, NM, 0);
-        SchedPin<G, NI, g + 1>::template run_n<NM>();
+        constexpr int per = (NV + G - 1) / G;  // VMEM per group
+        if constexpr (g * per < NV)
+            __builtin_amdgcn_sched_group_barrier(0x20, (g + 1) * per <= NV ? per : NV - g * per, 0);
+        SchedPin<G, NI, g + 1>::template run<NV>();
     }
 };
 template <int G, int NI>
 struct SchedPin<G, NI, G> {
+    template <int NV>
     static __device__ __forceinline__ void run() {}
-    template <int NM>
-    static __device__ __forceinline__ void run_n() {}
 };
 
+// Persistent kernel: gridDim.x workgroups (as many as are resident at once) each walk the tiles
+// bid, bid + gridDim.x, ... (the same XCD every time).  The K loop runs as ONE stream across tile
+// boundaries: the last slab iteration of a tile stages the first slab of the next tile, so neither the
+// next tile's first-load latency nor the drain of this tile's epilogue stores is exposed.
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
@@ -361,6 +362,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     constexpr int A_ITERS = (BM / 8) / NW, B_ITERS = (BN / 8) / NW;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split over waves");
     static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small for the wave count");
+    // the epilogue's transposition scratch must fit in ONE stage: the other one already holds the
+    // next tile's first slab
+    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, STAGE_BYTES);
+    static_assert(NW * 16 * MI_CH * (TN * 4 + 16) <= STAGE_BYTES, "epilogue scratch exceeds a stage");
     typedef typename MfmaOp<T>::frag frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,57 +374,62 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
 
-    int m0, n0;
-    tile_origin<BM, BN>(p, m0, n0);
-
-    // ---- per-lane source pointers for the staging loads ----
+    // ---- per-lane source pointers for the staging loads of one tile ----
     const int srow = lane >> 3;  // row within an 8-row LDS-DMA piece
     const int sslot = lane & 7;  // 16-byte slot written by this lane
-    const char* a_src[A_ITERS];
-    const char* w_src[B_ITERS];
+    struct TileSrc {
+        int m0, n0;
+        const char* a[A_ITERS];
+        const char* w[B_ITERS];
+    };
+    auto setup = [&](TileSrc& t, int vb) {
+        tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        const int row = (i * NW + wave) * 8 + srow;
-        const int chunk = sslot ^ ((row >> 1) & 7);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        if constexpr (AMODE == A_PLAIN) {
-            a_src[i] = (const char*)p.A + ((int64_t)gm * p.lda) * 2 + chunk * 16;
-        } else {
-            const int ppi = p.out_H * p.out_W;
-            const int b = gm / ppi;
-            const int rem = gm - b * ppi;
-            const int y = rem / p.out_W;
-            const int x = rem - y * p.out_W;
-            const int64_t pix = ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
-            a_src[i] = (const char*)p.A + pix * p.Cin * 2 + chunk * 16;
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int row = (i * NW + wave) * 8 + srow;
+            const int chunk = sslot ^ ((row >> 1) & 7);
+            int gm = t.m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            if constexpr (AMODE == A_PLAIN) {
+                t.a[i] = (const char*)p.A + ((int64_t)gm * p.lda) * 2 + chunk * 16;
+            } else {
+                const int ppi = p.out_H * p.out_W;
+                const int b = gm / ppi;
+                const int rem = gm - b * ppi;
+                const int y = rem / p.out_W;
+                const int x = rem - y * p.out_W;
+                const int64_t pix = ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
+                t.a[i] = (const char*)p.A + pix * p.Cin * 2 + chunk * 16;
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-        const int row = (i * NW + wave) * 8 + srow;
-        const int chunk = sslot ^ ((row >> 1) & 7);
-        int gn = n0 + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        w_src[i] = (const char*)p.W + ((int64_t)gn * p.K) * 2 + chunk * 16;
-    }
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int row = (i * NW + wave) * 8 + srow;
+            const int chunk = sslot ^ ((row >> 1) & 7);
+            int gn = t.n0 + row;
+            gn = gn < p.N ? gn : p.N - 1;
+            t.w[i] = (const char*)p.W + ((int64_t)gn * p.K) * 2 + chunk * 16;
+        }
+    };
 
     const int nk = p.K / 64;
     // A_CONV: K index = tap * Cin + cin; a 64-wide slab never straddles a tap (Cin % 64 == 0)
     const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
     const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
-    int tap_kc = 0, tap_ky = 0, tap_kx = 0;  // scalar state for the slab being staged
+    int tap_kc = 0, tap_ky = 0, tap_kx = 0;  // scalar state of the slab being staged
 
-    auto stage = [&](int kt, int buf) {
-        char* la = smem + buf * STAGE_BYTES;
-        char* lb = la + A_BYTES;
-        int64_t a_koff;
+    // Staging of slab kt of tile t into LDS buffer buf, split so that the caller can place the
+    // A_ITERS + B_ITERS LDS-DMA instructions one by one between MFMA groups (slabs are staged in order:
+    // kt = 0 resets the taps).
+    auto stage_a_offset = [&](int kt) -> int64_t {
         if constexpr (AMODE == A_PLAIN) {
-            a_koff = (int64_t)kt * 128;
+            return (int64_t)kt * 128;
         } else {
-            a_koff = ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 +
-                     tap_kc * 128;
+            if (kt == 0) tap_kc = tap_ky = tap_kx = 0;
+            const int64_t off =
+                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
             if (++tap_kc == cin_steps) {
                 tap_kc = 0;
                 if (++tap_kx == p.KW) {
@@ -427,272 +437,137 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                     ++tap_ky;
                 }
             }
+            return off;
         }
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) glds16(a_src[i] + a_koff, la + (i * NW + wave) * 1024);
-        const int64_t w_koff = (int64_t)kt * 128;
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) glds16(w_src[i] + w_koff, lb + (i * NW + wave) * 1024);
     };
-
-    f32x4 acc[MI][NI];
+    auto stage_piece = [&](const TileSrc& t, int piece, int64_t a_koff, int64_t w_koff, int buf) {
+        char* la = smem + buf * STAGE_BYTES;
+        if (piece < A_ITERS)
+            glds16(t.a[piece] + a_koff, la + (piece * NW + wave) * 1024);
+        else
+            glds16(t.w[piece - A_ITERS] + w_koff, la + A_BYTES + ((piece - A_ITERS) * NW + wave) * 1024);
+    };
+    auto stage = [&](const TileSrc& t, int kt, int buf) {
+        const int64_t a_koff = stage_a_offset(kt), w_koff = (int64_t)kt * 128;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < A_ITERS + B_ITERS; ++i) stage_piece(t, i, a_koff, w_koff, buf);
+    };
 
     // fragment read addressing (byte offsets inside a stage)
     const int frow = lane & 15;
     const int fswz = frow >> 1;
-    const int fslot0 = ((lane >> 4) ^ fswz) * 16;      // k-substep 0
+    const int fslot0 = ((lane >> 4) ^ fswz) * 16;        // k-substep 0
     const int fslot1 = (((lane >> 4) + 4) ^ fswz) * 16;  // k-substep 1
     const int a_rd = (wm * TM + frow) * 128;
     const int b_rd = A_BYTES + (wn * TN + frow) * 128;
 
-    if (p.debug < 5) stage(0, 0);
+    int vb = blockIdx.x;
+    TileSrc cur, nxt;
+    setup(cur, vb);
+    stage(cur, 0, 0);
     __syncthreads();
-    if (p.debug == 6) return;
+    int buf = 0;
+    [[maybe_unused]] int stamp_i = 0;
+#ifdef ME_GEMM_STAMPS
+#define ME_STAMP()                                                                       \
+    do {                                                                                 \
+        if (p.stamps && tid == 0 && stamp_i < 16)                                        \
+            p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define ME_STAMP() do {} while (0)
+#endif
+    ME_STAMP();
 
-    if (p.debug == 4) {  // development: MFMA issue floor
-        frag a0 = *reinterpret_cast<const frag*>(smem + a_rd + fslot0);
-        frag w0 = *reinterpret_cast<const frag*>(smem + b_rd + fslot0);
+    while (true) {
+        const bool has_next = vb + (int)gridDim.x < ntiles;
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
         for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-            for (int rep = 0; rep < 2; ++rep)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = MfmaOp<T>::run(w0, a0, acc[i][j]);
-            asm volatile("" : "+v"(a0), "+v"(w0));
-        }
-    }
-    for (int kt = 0; kt < nk && p.debug < 3; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk && p.debug != 2) stage(kt + 1, buf ^ 1);
-        const char* sb = smem + buf * STAGE_BYTES;
-        if (p.debug != 1) {
-            // Software-pipelined fragment feed.  The 2*MI "groups" (k-substep kk, m-tile i) each
-            // issue NI MFMAs on one A fragment; the A fragment of group g+2 and (early on) the W
-            // fragments of the second k-substep are read from LDS while group g's MFMAs run, so after
-            // the first two groups no MFMA waits for an LDS round trip.
-            constexpr int G = 2 * MI;
-            frag af[G], wf[2][NI];
-            auto rd_a = [&](int g) {
-                return *reinterpret_cast<const frag*>(sb + a_rd + (g % MI) * 2048 +
-                                                      (g < MI ? fslot0 : fslot1));
-            };
-            auto rd_w = [&](int kk, int j) {
-                return *reinterpret_cast<const frag*>(sb + b_rd + j * 2048 + (kk == 0 ? fslot0 : fslot1));
-            };
-#pragma unroll
-            for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
-            af[0] = rd_a(0);
-            if (G > 1) af[1] = rd_a(1);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (g + 2 < G) af[g + 2] = rd_a(g + 2);
-                if (g < NI) wf[1][g] = rd_w(1, g);
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[g % MI][j] = MfmaOp<T>::run(wf[g < MI ? 0 : 1][j], af[g], acc[g % MI][j]);
+            if (kt + 1 < nk) {
+                stage(cur, kt + 1, buf ^ 1);
+            } else if (has_next) {
+                setup(nxt, vb + gridDim.x);
+                stage(nxt, 0, buf ^ 1);
             }
-            // pin that order: (reads of the group, then its NI MFMAs) x G
-            __builtin_amdgcn_sched_group_barrier(0x100, NI + (G > 1 ? 2 : 1), 0);
-            SchedPin<G, NI, 0>::run();
-        }
-        __syncthreads();
-    }
-
-    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, 2 * STAGE_BYTES);
-    gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(p, acc, m0, n0, wm, wn, lane,
-                                                 smem + wave * (16 * MI_CH * (TN * 4 + 16)));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ring main loop: 32-deep K slabs in an NS-slot LDS ring, LDS-DMA running NS-1 slabs ahead of the
-// MFMAs, ONE raw s_barrier per slab and a counted `s_waitcnt vmcnt(N)` that leaves the younger slabs
-// in flight across the barrier (cdna_hip_programming.md §5 "Pipelining across barriers", T3/T4).
-// LDS rows are 64 bytes (4 chunks of 16 B); chunk c of row r sits at slot c ^ ((-(r >> 2)) & 3), which
-// spreads every ds_read_b128 lane group over all 16 slots of the 256-byte bank row.
-// ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_barrier() {
-    // one statement: the wait retires this wave's share of the slab, the barrier publishes everyone's
-    // and frees the slot the next LDS-DMA overwrites; "memory" keeps LDS accesses on their side
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NS, int AMODE, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams p) {
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_ITERS = (BM / 16) / NW, B_ITERS = (BN / 16) / NW;  // 1 KiB piece = 16 rows x 64 B
-    constexpr int PER_STAGE = A_ITERS + B_ITERS;                       // LDS-DMA instructions per wave
-    static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile rows must split over waves");
-    static_assert(NS >= 3 && (NS - 2) * PER_STAGE <= 63, "ring depth");
-    typedef typename MfmaOp<T>::frag frag;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int m0, n0;
-    tile_origin<BM, BN>(p, m0, n0);
-
-    // staging: lane -> row (lane >> 2) of a 16-row piece, slot lane & 3
-    const int srow = lane >> 2, sslot = lane & 3;
-    const int schunk = sslot ^ ((4 - (lane >> 4)) & 3);  // piece bases are multiples of 16 rows
-    const char* a_src[A_ITERS];
-    const char* w_src[B_ITERS];
+            const char* sb = smem + buf * STAGE_BYTES;
+            {
+                // Software-pipelined fragment feed.  The 2*MI "groups" (k-substep kk, m-tile i) each
+                // issue NI MFMAs on one A fragment; the A fragment of group g+2 and (early on) the W
+                // fragments of the second k-substep are read from LDS while group g's MFMAs run, so
+                // after the first two groups no MFMA waits for an LDS round trip.  (Spreading the next
+                // slab's LDS-DMA instructions between the groups as well was measured and lost.)
+                constexpr int G = 2 * MI;
+                frag af[G], wf[2][NI];
+                auto rd_a = [&](int g) {
+                    return *reinterpret_cast<const frag*>(sb + a_rd + (g % MI) * 2048 +
+                                                          (g < MI ? fslot0 : fslot1));
+                };
+                auto rd_w = [&](int kk, int j) {
+                    return *reinterpret_cast<const frag*>(sb + b_rd + j * 2048 +
+                                                          (kk == 0 ? fslot0 : fslot1));
+                };
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        int gm = m0 + (i * NW + wave) * 16 + srow;
-        gm = gm < p.M ? gm : p.M - 1;
-        if constexpr (AMODE == A_PLAIN) {
-            a_src[i] = (const char*)p.A + ((int64_t)gm * p.lda) * 2 + schunk * 16;
-        } else {
-            const int ppi = p.out_H * p.out_W;
-            const int b = gm / ppi;
-            const int rem = gm - b * ppi;
-            const int y = rem / p.out_W;
-            const int x = rem - y * p.out_W;
-            const int64_t pix = ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
-            a_src[i] = (const char*)p.A + pix * p.Cin * 2 + schunk * 16;
-        }
-    }
+                for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
+                af[0] = rd_a(0);
+                if (G > 1) af[1] = rd_a(1);
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-        int gn = n0 + (i * NW + wave) * 16 + srow;
-        gn = gn < p.N ? gn : p.N - 1;
-        w_src[i] = (const char*)p.W + ((int64_t)gn * p.K) * 2 + schunk * 16;
-    }
-
-    const int ns = p.K / 32;
-    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 32 : 1;
-    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
-    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
-
-    auto stage = [&](int s, int slot) {
-        char* la = smem + slot * STAGE_BYTES;
-        char* lb = la + A_BYTES;
-        int64_t a_koff;
-        if constexpr (AMODE == A_PLAIN) {
-            a_koff = (int64_t)s * 64;
-        } else {
-            a_koff = ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 +
-                     tap_kc * 64;
-            if (++tap_kc == cin_steps) {
-                tap_kc = 0;
-                if (++tap_kx == p.KW) {
-                    tap_kx = 0;
-                    ++tap_ky;
+                for (int g = 0; g < G; ++g) {
+                    if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+                    if (g < NI) wf[1][g] = rd_w(1, g);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[g % MI][j] = MfmaOp<T>::run(wf[g < MI ? 0 : 1][j], af[g], acc[g % MI][j]);
                 }
+                // pin that order: (reads of the group, then its NI MFMAs) x G
+                __builtin_amdgcn_sched_group_barrier(0x100, NI + (G > 1 ? 2 : 1), 0);
+                SchedPin<G, NI, 0>::template run<0>();
             }
+            __syncthreads();  // slab in buf^1 has landed (vmcnt(0)); everyone is done reading buf
+            buf ^= 1;
         }
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) glds16(a_src[i] + a_koff, la + (i * NW + wave) * 1024);
-        const int64_t w_koff = (int64_t)s * 64;
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) glds16(w_src[i] + w_koff, lb + (i * NW + wave) * 1024);
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15;
-    const int fslot = ((lane >> 4) ^ ((4 - (frow >> 2)) & 3)) * 16;
-    const int a_rd = (wm * TM + frow) * 64 + fslot;
-    const int b_rd = A_BYTES + (wn * TN + frow) * 64 + fslot;
-
-    // prologue: NS-1 slabs in flight
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < ns) stage(s, s);
-
-    int slot = 0;
-    for (int s = 0; s < ns; ++s) {
-        // slabs younger than s that may stay in flight: min(NS-2, ns-1-s)
-        const int younger = ns - 1 - s;
-        if (younger >= NS - 2)
-            wait_vmcnt_barrier<(NS - 2) * PER_STAGE>();
-        else if (NS > 3 && younger == 1)
-            wait_vmcnt_barrier<PER_STAGE>();
-        else
-            wait_vmcnt_barrier<0>();
-        static_assert(NS <= 4, "tail wait ladder written for NS <= 4");
-        if (s + NS - 1 < ns && p.debug != 2) {
-            int ps = slot + NS - 1;
-            ps = ps >= NS ? ps - NS : ps;
-            stage(s + NS - 1, ps);
-        }
-        const char* sb = smem + slot * STAGE_BYTES;
-        if (p.debug == 1) {
-            slot = slot + 1 == NS ? 0 : slot + 1;
-            continue;
-        }
-        {
-            // same software-pipelined fragment feed as the 2-stage kernel (one k-substep per slab)
-            frag af[MI], wf[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const frag*>(sb + b_rd + j * 1024);
-            af[0] = *reinterpret_cast<const frag*>(sb + a_rd);
-            if (MI > 1) af[1] = *reinterpret_cast<const frag*>(sb + a_rd + 1024);
-#pragma unroll
-            for (int g = 0; g < MI; ++g) {
-                if (g + 2 < MI) af[g + 2] = *reinterpret_cast<const frag*>(sb + a_rd + (g + 2) * 1024);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[g][j] = MfmaOp<T>::run(wf[j], af[g], acc[g][j]);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, NI + (MI > 1 ? 2 : 1), 0);
-            SchedPin<MI, 0, 0>::template run_n<NI>();
-        }
-        slot = slot + 1 == NS ? 0 : slot + 1;
+        ME_STAMP();
+        // buf now holds the next tile's first slab; buf^1 was consumed last and is the scratch
+        gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(
+            p, acc, cur.m0, cur.n0, wm, wn, lane,
+            smem + (buf ^ 1) * STAGE_BYTES + wave * (16 * MI_CH * (TN * 4 + 16)));
+        ME_STAMP();
+        if (!has_next) break;
+        // the scratch is restaged by the next tile's first iteration: its LDS reads must be done
+        __syncthreads();
+        cur = nxt;
+        vb += gridDim.x;
     }
-    __syncthreads();  // every wave is done with the ring before it becomes epilogue scratch
-    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, NS * STAGE_BYTES);
-    gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(p, acc, m0, n0, wm, wn, lane,
-                                                 smem + wave * (16 * MI_CH * (TN * 4 + 16)));
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int AMODE, int EPI>
-void gemm_launch_ring(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = NS * (BM + BN) * 64;
-    auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, NS, AMODE, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   smem));
-        attr_set = true;
-    }
-    const int64_t grid = cdiv(p.M, BM) * cdiv(p.N, BN);
-    ME_CHECK(grid > 0 && grid < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
-             (long long)grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
-    ME_HIP(hipGetLastError());
-}
+#undef ME_STAMP
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
     auto kern = gemm_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static int resident = 0;  // workgroups that fit on the chip at once (per instantiation)
+    if (!resident) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    smem));
-        attr_set = true;
+        int per_cu = 0, dev = 0, cus = 0;
+        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, WM * WN * 64,
+                                                            smem));
+        ME_HIP(hipGetDevice(&dev));
+        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        per_cu = per_cu < 1 ? 1 : per_cu;
+        resident = per_cu * cus;
+        resident -= resident % 8;  // whole XCD rounds: workgroup b always lands on XCD b % 8
+        resident = resident < 8 ? 8 : resident;
     }
-    const int64_t nbm = cdiv(p.M, BM), nbn = cdiv(p.N, BN);
-    const int64_t grid = nbm * nbn;
-    ME_CHECK(grid > 0 && grid < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
-             (long long)grid);
+    const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
+             (long long)ntiles);
+    const int64_t grid = ntiles < resident ? ntiles : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, stream, p);
     ME_HIP(hipGetLastError());
 }
@@ -709,8 +584,6 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 1: gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 256, 128, 4, 2, AMODE, EPI>(p, stream); break;     \
-            case 4: gemm_launch_ring<T, 256, 256, 2, 4, 4, AMODE, EPI>(p, stream); break; \
-            case 5: gemm_launch_ring<T, 256, 128, 4, 2, 4, AMODE, EPI>(p, stream); break; \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

@@ -83,8 +83,10 @@ struct me_ctx {
     int32_t dtype = ME_DTYPE_F16;
     me_model_config cfg;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side_stream = nullptr;  // image/FOV encoders run beside the patch encoder
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The two single-window ViTs (image encoder, FOV encoder: M = 577 GEMMs that cannot fill the chip)
+    // run on side streams beside the 35-window patch encoder.
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_img = nullptr, ev_fov = nullptr;
     std::string last_error;
     me_progress_fn progress = nullptr;
     void* progress_user = nullptr;
@@ -137,9 +139,11 @@ struct VitTaps {
 void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
                  void* final16, float* final32, const std::string& tag, hipStream_t stream);
 
-void stage_encoder(me_ctx* ctx, const float* img32, int B);
+// fov_async: also start the FOV encoder (ViT + linear) on a side stream; stage_fov_tail joins it
+void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async);
 void stage_decoder(me_ctx* ctx, int B, bool want_features32);
-void stage_fov(me_ctx* ctx, int B, float* fov_deg_dev);
+void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s);
+void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev, bool join_side_stream);
 // f_norm_dev [B]; clamp 0 = canonical (no clamp, f_norm ignored -> 1)
 void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
 

@@ -206,7 +206,7 @@ void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const Vit
 }
 
 // encoder.rs:218-335 DepthProEncoder::forward_encodings
-void stage_encoder(me_ctx* ctx, const float* img32, int B) {
+void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), S = ctx->S(), C = ctx->C(), P = ctx->P(), T = ctx->T();
@@ -220,6 +220,26 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B) {
     cast_f32_to_16_launch(img32, x0, (int64_t)B * 3 * S * S, ctx->dtype, s);
     bilinear_launch(img32, x1, 3 * B, S, S / 2, c.align_corners, ctx->dtype, s);
     bilinear_launch(img32, x2, 3 * B, S, S / 4, c.align_corners, ctx->dtype, s);
+    // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend
+    // only on x2, so they start now on the side streams and overlap the patch encoder
+    ME_HIP(hipEventRecord(ctx->ev_fork, s));
+    void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2);
+    {
+        hipStream_t s1 = ctx->side[0];
+        ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
+        void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
+        patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
+        void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
+        vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s1);
+        merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s1);
+        ME_HIP(hipEventRecord(ctx->ev_img, s1));
+    }
+    if (fov_async) {
+        hipStream_t s2 = ctx->side[1];
+        ME_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        stage_fov_vit(ctx, B, s2);
+        ME_HIP(hipEventRecord(ctx->ev_fov, s2));
+    }
     // encoder.rs:238-250 split + cat, vit.rs:210-223 patch embed im2col
     report(ctx, 0.02f, "preparing image patches");
     void* patches = site_buf(ctx, "enc.patches", (size_t)B * 35 * P * 768 * 2);
@@ -244,15 +264,6 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B) {
     merge_launch(nullptr, tok16, x1f, B, 35, 25, 3, g / 4, g, C, ctx->dtype, s);
     merge_launch(nullptr, tok16, x2f, B, 35, 34, 1, 0, g, C, ctx->dtype, s);
 
-    report(ctx, 0.6f, "encoding image");
-    // encoder.rs:298-303 image encoder on the 1/4 image
-    void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
-    patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s);
-    void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
-    vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s);
-    void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2);
-    merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s);
-
     report(ctx, 0.7f, "encoding features");
     // encoder.rs:307-316
     const int H0 = 32 * g, H1 = 16 * g, H2 = 8 * g, H3 = 4 * g, H4 = 2 * g;
@@ -271,6 +282,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B) {
     char* cat = (char*)site_buf(ctx, "enc.cat", (size_t)B * H4 * H4 * 2 * e3 * 2);
     run_upsample(ctx, "up2", x2f, B, g, ctx->w.up2, nullptr, cat, false, 2 * e3, ACT_NONE, s);
     report(ctx, 0.9f, "upsampling lowres");
+    ME_HIP(hipStreamWaitEvent(s, ctx->ev_img, 0));  // join the image encoder
     convt(ctx, xg, B, g, g, C, ctx->w.up_lowres_w, e3, ctx->w.up_lowres_b, nullptr, cat + (size_t)e3 * 2,
           false, 2 * e3, ACT_NONE, s);
     report(ctx, 0.95f, "fusing lowres");
@@ -395,22 +407,28 @@ void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* 
     gemm_launch(p, A_CONV, EPI_HEAD_FINAL, ctx->dtype, s);
 }
 
-// fov.rs:40-88 FOVNetwork::forward; needs "enc.x2" (the 1/4 image) and "lowres.f32"
-void stage_fov(me_ctx* ctx, int B, float* fov_deg_dev) {
-    hipStream_t s = ctx->stream;
-    const me_model_config& c = ctx->cfg;
-    const int g = ctx->g(), C = ctx->C(), P = ctx->P(), T = ctx->T(), dec = c.dec_dim;
+// fov.rs:40-63: the FOV encoder (third ViT-L on "enc.x2", the 1/4 image) and its Linear
+void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s) {
+    const int g = ctx->g(), C = ctx->C(), P = ctx->P(), T = ctx->T(), dec = ctx->cfg.dec_dim;
     report(ctx, 0.0f, "encoding fov");
     const void* x2 = ctx->bufs.at("enc.x2").p;
     void* patches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
     patchify_windows_launch(x2, patches, B, g, ctx->dtype, s);
     void* tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
     vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
-    report(ctx, 0.8f, "fov linear");
     float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
     linear(ctx, tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
            dec / 2, ACT_NONE, s);
+}
+
+// fov.rs:66-88: the convolutional tail; needs "fov.lin" (stage_fov_vit) and "lowres.f32" (decoder)
+void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev, bool join_side_stream) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), P = ctx->P(), T = ctx->T(), dec = c.dec_dim;
+    if (join_side_stream) ME_HIP(hipStreamWaitEvent(s, ctx->ev_fov, 0));
     report(ctx, 0.85f, "fov lowres");
+    const float* lin32 = (const float*)ctx->bufs.at("fov.lin").p;
     // fov.rs:70-74: relu(downsample[0](lowres)) + reshaped tokens
     const float* low32 = (const float*)ctx->bufs.at("lowres.f32").p;
     void* low16b = site_buf(ctx, "fov.low16b", bordered_bytes(B, 2 * g, 2 * g, dec));
