@@ -14,6 +14,8 @@
 //   operand"), V^T fragments come from ds_read_b64_tr_b16 on the row-major V tile.
 // tokens = 577 is not a multiple of 64: key rows past the end are clamped on load and masked
 // to -inf, query rows past the end are clamped on load and not stored.
+#include <type_traits>
+
 #include "common.h"
 
 namespace me {
@@ -122,9 +124,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     ME_ATT_WRITE_TILE(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One KV tile.  TAIL (last tile only) masks the keys past the end.  Softmax runs on raw scores:
+    // p = exp2(s*c - m*c) with c = scale*log2(e) folded into one FMA; O and l are rescaled only in the
+    // tiles where some lane's running max actually grows (exact, and rare after the first tiles).
+    auto tile = [&](int kt, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int buf = kt & 1;
-        if (kt + 1 < nkt) ME_ATT_LOAD_TILE(kt + 1);
+        if (!TAIL) ME_ATT_LOAD_TILE(kt + 1);
         const char* kb = smem + buf * TILE_BYTES;
         const char* vb = smem + (2 + buf) * TILE_BYTES;
 
@@ -140,39 +146,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                 s[ks] = Mfma32<T>::run(kf, qf[st], s[ks]);
             }
         }
-        // ---- scale, mask the tail keys, running max
-        const bool tail = (kt + 1) * KT > tokens;
+        // ---- running max on the raw scores
         float mloc = -1e30f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                float v = s[ks][g] * scale_log2e;
-                if (tail) {
+                if (TAIL) {
                     const int key = kt * KT + ks * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    v = key < tokens ? v : -INFINITY;
+                    if (key >= tokens) s[ks][g] = -INFINITY;
                 }
-                s[ks][g] = v;
-                mloc = fmaxf(mloc, v);
+                mloc = fmaxf(mloc, s[ks][g]);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(mloc > m_run)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) o[d][g] *= alpha;
+        }
+        const float mc = m_run * scale_log2e;
         float psum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float pv = exp2f(s[ks][g] - m_new);
+                // raw v_exp_f32: the argument is <= 0, results below 2^-126 may flush to 0
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks][g], scale_log2e, -mc));
                 s[ks][g] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) o[d][g] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -201,9 +209,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                 }
             }
 
-        if (kt + 1 < nkt) ME_ATT_WRITE_TILE(buf ^ 1);
+        if (!TAIL) ME_ATT_WRITE_TILE(buf ^ 1);
         __syncthreads();
-    }
+    };
+    for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type());
+    tile(nkt - 1, std::true_type());
 
     // ---- normalise and store: lane holds q = q0 + r, d = 32 dblk + 8 (g >> 2) + 4 h + (g & 3)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
