@@ -6,7 +6,10 @@ package is the host-side mirror of the reference's interface for that path
 There is no CPU fallback: every compute call raises `MatrixEyesError` when the library or a GPU
 is missing.
 """
+__version__ = "0.1.0"
+
 from .config import ModelConfig, expected_weights  # noqa: F401
 from ._lib import MatrixEyesError, load_library, library_path  # noqa: F401
 from .depth_pro import Context, DepthProModelLoader, IMG_SIZE  # noqa: F401
 from .output import DepthMap, ImageOutputFormat, VertexMode  # noqa: F401
+from .reconstruction import ReconstructionError, SourceImage, extract_depth  # noqa: F401

@@ -168,3 +168,42 @@ def test_extract_depth_full_size(dtype):
     print("full-size", dtype, rep, float(fov[0]), float(ref_fov[0]))
     assert rep["rel_l2"] < 2.0e-3
     assert abs(float(fov[0]) - float(ref_fov[0])) < 0.1
+
+
+def test_reconstruction_end_to_end_with_pt_checkpoint(tmp_path):
+    """reconstruction.rs:155-205 through the host mirror: photo file + PyTorch .pt checkpoint in,
+    depth-map PNG / stereogram PNG / OBJ+MTL out"""
+    from PIL import Image
+    cfg = m.ModelConfig.tiny()
+    ckpt = tmp_path / "depth_pro_tiny.pt"
+    torch.save(weights_for("tiny"), ckpt)                      # fp16 state dict, PyTorch names
+    loader = m.DepthProModelLoader(str(ckpt), False, cfg=cfg)
+    S = cfg.img_size
+    rgb = synthetic_images(1, S)[0]
+    photo = tmp_path / "photo.png"
+    Image.fromarray(rgb).save(photo)
+    seen = []
+    m.extract_depth(0, loader, str(photo), str(tmp_path / "depth.png"), None, m.ImageOutputFormat.DepthMap(),
+                    m.VertexMode.Color, progress=lambda pos, msg: seen.append(pos))
+    got = np.asarray(Image.open(tmp_path / "depth.png"))
+    assert got.shape == (S, S, 3) and seen[-1] == 1.0
+    # same depth as the synthetic-checkpoint context (the .pt path loads the same tensors)
+    ref_depth = loaded_ctx("tiny", "f16").extract_depth(rgb[None], None)[0]
+    dm = m.DepthMap(loaded_ctx("tiny", "f16"), ref_depth, (S, S))
+    assert np.array_equal(got, dm.depth_map_rgb())
+    m.extract_depth(0, loader, str(photo), str(tmp_path / "mesh.obj"), 50.0, m.ImageOutputFormat.DepthMap(),
+                    m.VertexMode.Texture)
+    text = (tmp_path / "mesh.obj").read_text()
+    assert text.startswith("mtllib mesh.mtl\nusemtl Textured\nvt ") and "\nf " in text
+    assert (tmp_path / "mesh.mtl").read_text().endswith(f"map_Kd {photo}\n\n")
+    noise = np.random.default_rng(7).integers(0, 256, size=(S, S, 3), dtype=np.uint8)
+    m.extract_depth(0, loader, str(photo), str(tmp_path / "stereo.png"), 50.0,
+                    m.ImageOutputFormat.Stereogram(None, 1 / 16), m.VertexMode.Plain, noise=noise)
+    assert np.asarray(Image.open(tmp_path / "stereo.png")).shape == (S, S, 3)
+    # a checkpoint with a missing tensor is refused like mod.rs:241-243
+    bad = dict(weights_for("tiny"))
+    del bad["fov.head.4.bias"]
+    torch.save(bad, tmp_path / "bad.pt")
+    with pytest.raises(m.MatrixEyesError) as e:
+        m.DepthProModelLoader(str(tmp_path / "bad.pt"), False, cfg=cfg).context(0)
+    assert e.value.code == 3
