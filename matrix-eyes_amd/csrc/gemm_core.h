@@ -16,6 +16,8 @@
 // (cols -> m): every lane then owns 4 consecutive n of one output row, so epilogues store
 // 16 B (f32) / 8 B (16-bit) per lane.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace me {
@@ -96,7 +98,7 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nw
 // (all waves) fits in the main loop's allocation
 constexpr int epi_mi_chunk(int MI, int TN, int NW, int main_bytes) {
     for (int c = 4; c >= 1; c >>= 1)
-        if (MI % c == 0 && NW * 16 * c * (TN * 4 + 16) <= main_bytes) return c;
+        if (MI % c == 0 && NW * 16 * c * (TN * 4) <= main_bytes) return c;
     return 1;
 }
 
@@ -131,12 +133,27 @@ __device__ __forceinline__ void store_16bit(T* dst, const float (&a)[8], bool hi
 }
 
 // v: accumulators of columns n + 4*h .. n + 4*h + 3 (h = 0, 1); hi_ok: the second half exists (n + 4 < N)
-template <typename T, int EPI>
+// MODE: 0 = every option checked at run time; 1 / 2 = the ViT fast paths of EPI_STORE (16-bit output
+// only, bias, no residual, no border; 1: no activation (qkv), 2: GELU (fc1)) with the branches gone
+template <typename T, int EPI, int MODE>
 __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiRow& r, int n,
                                                  const EpiLane& lc, const f32x4 (&v)[2], bool hi_ok) {
     const int m = r.m;
     float a[8];  // values for the 16-bit copy
-    if constexpr (EPI == EPI_STORE) {
+    if constexpr (EPI == EPI_STORE && MODE != 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
+            const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
+            if constexpr (MODE == 2) {
+                a[4 * h] = gelu_erf(x0), a[4 * h + 1] = gelu_erf(x1);
+                a[4 * h + 2] = gelu_erf(x2), a[4 * h + 3] = gelu_erf(x3);
+            } else {
+                a[4 * h] = x0, a[4 * h + 1] = x1, a[4 * h + 2] = x2, a[4 * h + 3] = x3;
+            }
+        }
+        store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
+    } else if constexpr (EPI == EPI_STORE) {
         const int64_t row32 = (int64_t)m * p.ldc;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -260,12 +277,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         }
     } else {
-        constexpr int RS = TN * 4 + 16;  // padded LDS row stride, bytes
+        // Scratch image: rows of TN f32 (TN*4 bytes, a multiple of 256), the 16-byte chunk c of row r kept
+        // at chunk position c ^ (r & 15): conflict-free for the transposing ds_write_b128 (16 rows, one
+        // chunk each) and for the row reads, without padding (two 16-row m-tiles of all 8 waves then
+        // fit exactly in one 64 KiB stage).
+        constexpr int RS = TN * 4;
         constexpr int ROWS = 16 * MI_CH;  // rows per pass
         constexpr int GPR = TN / 8;       // 8-column granules per row
         constexpr int RPI = 64 / GPR;     // rows covered by one wave-instruction
         constexpr int ITERS = ROWS / RPI;
         static_assert(MI % MI_CH == 0 && 64 % GPR == 0 && ROWS % RPI == 0, "epilogue pass shape");
+        static_assert(TN % 64 == 0 || TN == 32, "scratch swizzle assumes 16 chunks per row (8 for TN 32)");
+        constexpr int CMASK = TN / 4 - 1;  // chunks per row - 1
         const int gc = lane % GPR, r0 = lane / GPR;
         const int n = n0 + wn * TN + gc * 8;
         const bool n_ok = n < p.N, hi_ok = n + 4 < p.N;
@@ -298,31 +321,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             row.y = rem / p.out_W;
             row.x = rem - row.y * p.out_W;
         }
+        auto run = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-        for (int pass = 0; pass < MI / MI_CH; ++pass) {
+            for (int pass = 0; pass < MI / MI_CH; ++pass) {
 #pragma unroll
-            for (int i = 0; i < MI_CH; ++i)
+                for (int i = 0; i < MI_CH; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    *reinterpret_cast<f32x4*>(epi_lds + (i * 16 + frow) * RS + (j * 16 + ncol) * 4) =
-                        acc[pass * MI_CH + i][j];
-            // LDS operations of one wave execute in order: the reads below see the writes above
+                    for (int j = 0; j < NI; ++j)
+                        *reinterpret_cast<f32x4*>(epi_lds + (i * 16 + frow) * RS +
+                                                  ((((j * 16 + ncol) >> 2) ^ frow) & CMASK) * 16) =
+                            acc[pass * MI_CH + i][j];
+                // LDS operations of one wave execute in order: the reads below see the writes above
+                f32x4 v[ITERS][2];
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const char* src = epi_lds + (it * RPI + r0) * RS + gc * 32;
-                f32x4 v[2];
-                v[0] = *reinterpret_cast<const f32x4*>(src);
-                v[1] = *reinterpret_cast<const f32x4*>(src + 16);
-                if (row.m < p.M && n_ok) epilogue_granule<T, EPI>(p, row, n, lc, v, hi_ok);
-                row.m += RPI;
-                if (pix) {
-                    row.x += RPI;
-                    while (row.x >= p.out_W) {
-                        row.x -= p.out_W;
-                        if (++row.y == p.out_H) row.y = 0, ++row.b;
+                for (int it = 0; it < ITERS; ++it) {
+                    const int rr = it * RPI + r0;
+                    const char* src = epi_lds + rr * RS;
+                    v[it][0] = *reinterpret_cast<const f32x4*>(src + (((2 * gc) ^ rr) & CMASK) * 16);
+                    v[it][1] = *reinterpret_cast<const f32x4*>(src + (((2 * gc + 1) ^ rr) & CMASK) * 16);
+                }
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    if (row.m < p.M && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok);
+                    row.m += RPI;
+                    if (pix) {
+                        row.x += RPI;
+                        while (row.x >= p.out_W) {
+                            row.x -= p.out_W;
+                            if (++row.y == p.out_H) row.y = 0, ++row.b;
+                        }
                     }
                 }
             }
+        };
+        if constexpr (EPI == EPI_STORE) {
+            const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias;
+            if (simple && p.act == ACT_NONE)
+                run(std::integral_constant<int, 1>());
+            else if (simple && p.act == ACT_GELU)
+                run(std::integral_constant<int, 2>());
+            else
+                run(std::integral_constant<int, 0>());
+        } else {
+            run(std::integral_constant<int, 0>());
         }
     }
 }
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     // the epilogue's transposition scratch must fit in ONE stage: the other one already holds the
     // next tile's first slab
     constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, STAGE_BYTES);
-    static_assert(NW * 16 * MI_CH * (TN * 4 + 16) <= STAGE_BYTES, "epilogue scratch exceeds a stage");
+    static_assert(NW * 16 * MI_CH * (TN * 4) <= STAGE_BYTES, "epilogue scratch exceeds a stage");
     typedef typename MfmaOp<T>::frag frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -534,7 +576,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         // buf now holds the next tile's first slab; buf^1 was consumed last and is the scratch
         gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(
             p, acc, cur.m0, cur.n0, wm, wn, lane,
-            smem + (buf ^ 1) * STAGE_BYTES + wave * (16 * MI_CH * (TN * 4 + 16)));
+            smem + (buf ^ 1) * STAGE_BYTES + wave * (16 * MI_CH * (TN * 4)));
         ME_STAMP();
         if (!has_next) break;
         // the scratch is restaged by the next tile's first iteration: its LDS reads must be done
