@@ -32,6 +32,22 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_gemm.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of
+    tools/gemm_probe.py on the qkv and fc1 shapes, the two shapes this kernel alternates between in the
+    step).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced
+    stream (MI355X_MICROARCH.md, HBM), so it is doubled.  None for any other kernel."""
+    if kernel_name != "gemm_kernel<f16,256x256x64/8w,plain,store>":
+        return None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+        per = [(2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0 for k in ("qkv", "fc1")]
+        return sum(per) / len(per)
+    except Exception:
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +222,10 @@ def main():
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(dom["kernel"]),
+                "algorithmic_bytes": (None if dom["kernel"] != "gemm_kernel<f16,256x256x64/8w,plain,store>"
+                                      else 0.5 * ((20195 * 1024 + 3072 * 1024 + 20195 * 3072) * 2 +
+                                                  (20195 * 1024 + 4096 * 1024 + 20195 * 4096) * 2)),
                 "share_of_profiled_kernel_time": round(dom["total_ms"] / prof_ms, 3),
                 "whole_step_frac": round(value / world * tflop_img / MFMA_PEAK_TFLOPS, 4),
             },
