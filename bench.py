@@ -126,15 +126,15 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     # ---- weights: rank 0 parses/packs, one RCCL broadcast of the arena
-    weights = None
+    weights = {}
     t_load = time.perf_counter()
-    if rank == 0:
-        weights = synthetic_checkpoint(cfg)          # seed 2024; real depth_pro.pt is not available offline
-        ctx.load_state_dict(weights)
-    if distributed:
-        ids = [ctx.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.bcast_weights(ids[0], rank, world)
+
+    def make_weights():
+        weights.update(synthetic_checkpoint(cfg))   # seed 2024; the real depth_pro.pt is not available offline
+        return weights
+
+    from matrix_eyes_amd import distributed as D
+    D.distribute_weights(ctx, make_weights, rank, world)
     t_load = time.perf_counter() - t_load
 
     # ---- inputs resident in HBM before the timed region
@@ -208,7 +208,7 @@ def main():
                 "images": "u8 [B,1536,1536,3] synthetic 'structured' (seed 4321 + rank), resident in HBM",
                 "checkpoint": "synthetic, seed 2024, exact key set, 951.99 M parameters rounded to fp16",
                 "f_norm": "1.0" if args.no_fov else "FOV head (mod.rs:343-358)",
-                "parallelism": f"image-parallel, {world} process(es), one per GPU; weights by one RCCL "
+                "parallelism": f"image-parallel, {world} process(es), one per GPU; packed weights by one RCCL "
                                f"broadcast at start-up ({t_load:.1f} s incl. synthetic init)",
                 "tflop_per_image": tflop_img,
                 "model_tflops": round(value * tflop_img, 1),

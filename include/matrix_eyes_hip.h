@@ -124,6 +124,11 @@ int32_t me_expected_weight(const me_ctx* ctx, int32_t index, const char** name, 
 int32_t me_weights_finalize(me_ctx* ctx);
 /* Size of the packed device weight arena, bytes. */
 int64_t me_weight_arena_bytes(const me_ctx* ctx);
+/* Device address of the arena, for a caller that moves the packed weights with its own collective
+   (e.g. torch.distributed's RCCL communicator) instead of me_bcast_weights; after the bytes have
+   arrived on a rank, me_weights_adopt marks every tensor loaded and finalizes. */
+void* me_weight_arena_ptr(const me_ctx* ctx);
+int32_t me_weights_adopt(me_ctx* ctx);
 
 /* ---- multi-GPU start-up: one RCCL broadcast of the packed arena, no collective later ---
    rank 0 finalizes its weights, every rank calls me_bcast_weights with the same 128-byte id

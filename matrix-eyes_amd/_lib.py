@@ -49,6 +49,8 @@ SIGNATURES = {
     "me_expected_weight": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i32)]),
     "me_weights_finalize": (_i32, [_vp]),
     "me_weight_arena_bytes": (_i64, [_vp]),
+    "me_weight_arena_ptr": (_vp, [_vp]),
+    "me_weights_adopt": (_i32, [_vp]),
     "me_rccl_unique_id": (_i32, [_vp]),
     "me_bcast_weights": (_i32, [_vp, _vp, _i32, _i32]),
     "me_preprocess_u8": (_i32, [_vp, _vp, _i32, _vp]),

@@ -224,6 +224,15 @@ int32_t me_weights_finalize(me_ctx* ctx) {
 
 int64_t me_weight_arena_bytes(const me_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
 
+void* me_weight_arena_ptr(const me_ctx* ctx) { return ctx ? (void*)ctx->arena : nullptr; }
+
+int32_t me_weights_adopt(me_ctx* ctx) {
+    ME_API_BEGIN(ctx)
+    for (WeightSlot& s : ctx->slots) s.loaded = true;
+    ctx->finalized = true;
+    ME_API_END(ctx)
+}
+
 // ---- forward passes ----------------------------------------------------------------------
 int32_t me_preprocess_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, float* img) {
     ME_API_BEGIN(ctx)

@@ -145,6 +145,21 @@ class Context:
     def weight_arena_bytes(self) -> int:
         return int(self.lib.me_weight_arena_bytes(self._h))
 
+    def weight_arena_tensor(self):
+        """The packed weight arena as a zero-copy uint8 torch tensor on this context's GPU (for a
+        caller-side collective)."""
+        import torch
+
+        class _DevMem:
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                                 "data": (ptr, False), "version": 2}
+        ptr = self.lib.me_weight_arena_ptr(self._h)
+        return torch.as_tensor(_DevMem(int(ptr), self.weight_arena_bytes()), device="cuda")
+
+    def adopt_weights(self):
+        self._check(self.lib.me_weights_adopt(self._h))
+
     def bcast_weights(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(unique_id, 128)
         self._check(self.lib.me_bcast_weights(self._h, buf, rank, nranks))

@@ -57,11 +57,26 @@ def barrier():
         dist.barrier()
 
 
-def distribute_weights(ctx, state_dict_fn, rank: int, world: int):
-    """rank 0 loads (state_dict_fn() -> name -> tensor) and finalizes; everyone then takes part in
-    the single RCCL broadcast of the packed arena (me_bcast_weights)."""
+def distribute_weights(ctx, state_dict_fn, rank: int, world: int, native: Optional[bool] = None):
+    """rank 0 loads (state_dict_fn() -> name -> tensor) and finalizes; then ONE broadcast of the packed
+    arena (1.9 GB at f16) reaches the other ranks over xGMI.
+
+    Default: the broadcast runs on torch.distributed's existing RCCL communicator (backend "nccl"), on
+    the arena wrapped zero-copy as a uint8 tensor — one RCCL instance and one bootstrap per process.
+    native=True (or ME_NATIVE_RCCL=1) uses the library's own communicator instead (me_bcast_weights:
+    the path a non-Python caller takes)."""
+    if native is None:
+        native = os.environ.get("ME_NATIVE_RCCL", "0") == "1"
     if rank == 0:
         ctx.load_state_dict(state_dict_fn())
-    if world > 1:
+    if world <= 1:
+        return
+    if native:
         uid = broadcast_bytes(ctx.rccl_unique_id() if rank == 0 else None, 0)
         ctx.bcast_weights(uid, rank, world)
+        return
+    arena = ctx.weight_arena_tensor()
+    dist.broadcast(arena, src=0)
+    torch.cuda.synchronize()
+    if rank != 0:
+        ctx.adopt_weights()

@@ -143,6 +143,25 @@ def test_missing_and_unexpected_weights():
     ctx.close()
 
 
+def test_weight_arena_handover():
+    """The multi-GPU start-up path on one GPU: a second context receives only the packed arena bytes
+    (what the broadcast delivers), adopts them and must produce bit-identical depth."""
+    src = loaded_ctx("tiny", "f16")
+    dst = m.Context(0, "f16", src.cfg)
+    a, b = src.weight_arena_tensor(), dst.weight_arena_tensor()
+    assert a.dtype == torch.uint8 and a.numel() == src.weight_arena_bytes() == b.numel()
+    with pytest.raises(m.MatrixEyesError):               # nothing loaded yet
+        dst.extract_depth(synthetic_images(1, src.cfg.img_size), 1.0)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    dst.adopt_weights()
+    rgb = synthetic_images(1, src.cfg.img_size)
+    d0, f0 = src.extract_depth(rgb, None, want_fov=True)
+    d1, f1 = dst.extract_depth(rgb, None, want_fov=True)
+    assert np.array_equal(d0, d1) and f0[0] == f1[0]
+    dst.close()
+
+
 def test_progress_callback():
     ctx = loaded_ctx("tiny", "f16")
     seen = []
