@@ -113,11 +113,16 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # ME_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses
+    # two ranks on one device); the driver's runs use the default, nccl = RCCL, one GPU per rank
+    backend = os.environ.get("ME_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     cfg = m.ModelConfig()
     ctx = m.Context(local_rank, args.dtype, cfg)

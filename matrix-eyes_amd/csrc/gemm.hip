@@ -52,20 +52,36 @@ ProfScope::~ProfScope() {
     if (index >= 0) (void)hipEventRecord(profiler().entries[index].e1, stream);
 }
 
-static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w"};
-int gemm_num_configs() { return 4; }
-const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 4 ? kCfgNames[cfg] : "?"; }
+static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w",
+                                  "160x128x64/4w"};
+int gemm_num_configs() { return 5; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 5 ? kCfgNames[cfg] : "?"; }
 
-// Measured on MI355X (profiles/r01_kernel_microbench_f16.json): the 256x256 tile wins when there are
-// >= ~1.5 rounds of 256 workgroups and N is wide (qkv, fc1); the 128x128 tile (two workgroups per CU,
-// so one's epilogue overlaps the other's MFMAs) wins for N <= 1024 (proj, fc2, the 256-channel
-// convolutions); the 64x64 tile is for the single-window ViTs and the low-resolution decoder levels.
+// Tile choice.  The persistent kernel runs ceil(tiles / resident workgroups) rounds, so the cost of a
+// configuration is rounds x (tile area) x (workgroups sharing a CU) / (its main-loop efficiency relative
+// to the 256x256 tile, measured at M = 80780 where rounds do not matter: profiles/
+// r01_kernel_microbench_f16.json).  Examples at M = 20195: qkv / fc1 (N = 3072 / 4096) -> 256x256 (4 and
+// 5 rounds); proj / fc2 (N = 1024) -> 160x128: 1016 tiles = 2 rounds of 512, where 128x128 needs 3
+// (fc2 0.201 -> 0.175 ms); the 768^2 256-channel convolutions -> 256x256 (9 rounds exactly).
+// The 64x64 tile is for the single-window ViTs (M = 577) and the low-resolution decoder levels.
 static int pick_config(int64_t M, int64_t N) {
-    const int64_t t0 = cdiv(M, 256) * cdiv(N, 256);
-    if (N >= 2048 && t0 >= 400) return 0;
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
-    if (N >= 128 && t1 >= 256) return 1;
-    return 2;
+    if (N < 128 || t1 < 256) return 2;
+    struct Cand {
+        int cfg, bm, bn, per_cu;
+        double eff;
+    };
+    static const Cand cands[] = {{0, 256, 256, 1, 1.0}, {4, 160, 128, 2, 0.89}, {1, 128, 128, 2, 0.85}};
+    int best = 1;
+    double best_cost = 0.0;
+    for (const Cand& c : cands) {
+        if (N < c.bn) continue;
+        const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
+        const int64_t rounds = cdiv(tiles, (int64_t)256 * c.per_cu);
+        const double cost = (double)rounds * c.bm * c.bn * c.per_cu / c.eff;
+        if (best_cost == 0.0 || cost < best_cost) best = c.cfg, best_cost = cost;
+    }
+    return best;
 }
 
 template <typename T>

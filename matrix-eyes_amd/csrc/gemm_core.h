@@ -395,7 +395,7 @@ struct SchedPin<G, NI, G> {
 // boundaries: the last slab iteration of a tile stages the first slab of the next tile, so neither the
 // next tile's first-load latency nor the drain of this tile's epilogue stores is exposed.
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -516,8 +516,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         if (p.stamps && tid == 0 && stamp_i < 16)                                        \
             p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+    // per-wave phase accounting (shader clocks): [0] LDS-DMA issue, [1] fragment reads + MFMAs,
+    // [2] s_waitcnt vmcnt(0), [3] barrier; written behind the tile stamps
+    unsigned long long ph[4] = {0, 0, 0, 0}, pt = 0;
+#define ME_PHASE(i)                                              \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        if ((i) >= 0) ph[(i) < 0 ? 0 : (i)] += t_ - pt;          \
+        pt = t_;                                                 \
+    } while (0)
 #else
 #define ME_STAMP() do {} while (0)
+#define ME_PHASE(i) do {} while (0)
 #endif
     ME_STAMP();
 
@@ -530,12 +542,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int kt = 0; kt < nk; ++kt) {
+            ME_PHASE(-1);
             if (kt + 1 < nk) {
                 stage(cur, kt + 1, buf ^ 1);
             } else if (has_next) {
                 setup(nxt, vb + gridDim.x);
                 stage(nxt, 0, buf ^ 1);
             }
+            ME_PHASE(0);
             const char* sb = smem + buf * STAGE_BYTES;
             {
                 // Software-pipelined fragment feed.  The 2*MI "groups" (k-substep kk, m-tile i) each
@@ -569,7 +583,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x100, NI + (G > 1 ? 2 : 1), 0);
                 SchedPin<G, NI, 0>::template run<0>();
             }
+#ifdef ME_GEMM_STAMPS
+            ME_PHASE(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ME_PHASE(2);
+#endif
             __syncthreads();  // slab in buf^1 has landed (vmcnt(0)); everyone is done reading buf
+            ME_PHASE(3);
             buf ^= 1;
         }
         ME_STAMP();
@@ -578,7 +598,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             p, acc, cur.m0, cur.n0, wm, wn, lane,
             smem + (buf ^ 1) * STAGE_BYTES + wave * (16 * MI_CH * (TN * 4)));
         ME_STAMP();
-        if (!has_next) break;
+        if (!has_next) {
+#ifdef ME_GEMM_STAMPS
+            if (p.stamps && lane == 0)
+                for (int i = 0; i < 4; ++i)
+                    p.stamps[(size_t)gridDim.x * 16 + ((size_t)blockIdx.x * NW + wave) * 4 + i] = ph[i];
+#endif
+            break;
+        }
         // the scratch is restaged by the next tile's first iteration: its LDS reads must be done
         __syncthreads();
         cur = nxt;
@@ -587,6 +614,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 }
 
 #undef ME_STAMP
+#undef ME_PHASE
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
@@ -626,6 +654,7 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 1: gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 256, 128, 4, 2, AMODE, EPI>(p, stream); break;     \
+            case 4: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

@@ -220,10 +220,26 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     cast_f32_to_16_launch(img32, x0, (int64_t)B * 3 * S * S, ctx->dtype, s);
     bilinear_launch(img32, x1, 3 * B, S, S / 2, c.align_corners, ctx->dtype, s);
     bilinear_launch(img32, x2, 3 * B, S, S / 4, c.align_corners, ctx->dtype, s);
-    // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend
-    // only on x2, so they start now on the side streams and overlap the patch encoder
     ME_HIP(hipEventRecord(ctx->ev_fork, s));
     void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2);
+    // encoder.rs:238-250 split + cat, vit.rs:210-223 patch embed im2col
+    report(ctx, 0.02f, "preparing image patches");
+    void* patches = site_buf(ctx, "enc.patches", (size_t)B * 35 * P * 768 * 2);
+    patchify_launch(x0, x1, x2, patches, B, g, ctx->dtype, s);
+
+    report(ctx, 0.03f, "encoding patches");
+    const int side0 = 4 * g, side1 = 2 * g;
+    void* lat0 = site_buf(ctx, "enc.lat0", (size_t)B * side0 * side0 * C * 2);
+    void* lat1 = site_buf(ctx, "enc.lat1", (size_t)B * side0 * side0 * C * 2);
+    void* tok16 = site_buf(ctx, "enc.tok16", (size_t)B * 35 * T * C * 2);
+    TapCtx tc{ctx, B, lat0, lat1, s};
+    VitTaps taps;
+    taps.fn = tap_fn, taps.user = &tc;
+    vit_forward(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, tok16, nullptr, "vit.patch", s);
+    // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend
+    // only on x2, so they run on the side streams beside the patch encoder.  They are ENQUEUED after it:
+    // the host needs ~3 ms to issue their ~400 small launches, and the main stream must not sit empty
+    // meanwhile (it did: 3.8 ms of the step, rocprofv3 trace); they still finish long before the joins.
     {
         hipStream_t s1 = ctx->side[0];
         ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
@@ -240,20 +256,6 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
         stage_fov_vit(ctx, B, s2);
         ME_HIP(hipEventRecord(ctx->ev_fov, s2));
     }
-    // encoder.rs:238-250 split + cat, vit.rs:210-223 patch embed im2col
-    report(ctx, 0.02f, "preparing image patches");
-    void* patches = site_buf(ctx, "enc.patches", (size_t)B * 35 * P * 768 * 2);
-    patchify_launch(x0, x1, x2, patches, B, g, ctx->dtype, s);
-
-    report(ctx, 0.03f, "encoding patches");
-    const int side0 = 4 * g, side1 = 2 * g;
-    void* lat0 = site_buf(ctx, "enc.lat0", (size_t)B * side0 * side0 * C * 2);
-    void* lat1 = site_buf(ctx, "enc.lat1", (size_t)B * side0 * side0 * C * 2);
-    void* tok16 = site_buf(ctx, "enc.tok16", (size_t)B * 35 * T * C * 2);
-    TapCtx tc{ctx, B, lat0, lat1, s};
-    VitTaps taps;
-    taps.fn = tap_fn, taps.user = &tc;
-    vit_forward(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, tok16, nullptr, "vit.patch", s);
 
     report(ctx, 0.55f, "reshaping patch encodings");
     // encoder.rs:263,285-294: split_with_sizes + merge

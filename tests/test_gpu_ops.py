@@ -22,7 +22,7 @@ def _check(ctx, rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, -1])
 @pytest.mark.parametrize("shape", [(577, 256, 128), (1000, 132, 192), (2309, 384, 256), (5000, 512, 64)])
 def test_linear(dtype, cfg, shape):
     M, N, K = shape
@@ -57,7 +57,7 @@ def test_linear_gelu(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_linear_residual(dtype, cfg):
     M, N, K = 1154, 256, 512
     ctx = ctx_for("tiny", dtype)
@@ -137,7 +137,7 @@ def test_layernorm(dtype, dim):
     dict(B=1, H=12, W=12, Cin=64, Cout=32, k=3, stride=2),
     dict(B=1, H=20, W=20, Cin=128, Cout=64, k=1, stride=1),
 ])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_conv2d(dtype, case, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout, k, s = (case[n] for n in ("B", "H", "W", "Cin", "Cout", "k", "stride"))
@@ -172,7 +172,7 @@ def test_conv2d(dtype, case, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_conv_transpose(dtype, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout = 2, 18, 18, 128, 64

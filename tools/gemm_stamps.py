@@ -20,8 +20,12 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 1), (4096,
         if rc: print("rc", rc, lib.me_last_error(h))
         ctx.synchronize()
     lib.me_debug_set_stamps(None)
-    s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
-    s = s[s[:, 0] > 0]
+    raw = stamps.cpu().numpy()
+    s = raw.reshape(-1, 16).astype(np.float64)
+    nwg = int(np.sum(s[:256, 0] > 0)) if cfg == 0 else int(np.sum(s[:512, 0] > 0))
+    nw = 8 if cfg in (0, 3) else 4
+    ph = raw[nwg * 16: nwg * 16 + nwg * nw * 4].reshape(nwg, nw, 4).astype(np.float64)
+    s = s[:nwg]
     t0 = s[:, 0].min()
     us = (s - t0) / 100.0   # 100 MHz
     us[s == 0] = np.nan
@@ -33,3 +37,8 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 1), (4096,
         prev = us[:, 0] if t == 0 else us[:, ee - 2]
         print(f"  tile {t}: n={np.sum(~np.isnan(us[:, me]))} main {np.nanmean(us[:, me] - prev):.2f} us (min {np.nanmin(us[:, me] - prev):.2f} max {np.nanmax(us[:, me] - prev):.2f})"
               f"  epilogue {np.nanmean(us[:, ee] - us[:, me]):.2f} us (min {np.nanmin(us[:, ee] - us[:, me]):.2f} max {np.nanmax(us[:, ee] - us[:, me]):.2f})  start spread {np.nanstd(prev):.2f}")
+    tot = ph.sum(axis=2)
+    print("  phase cycles per wave (mean over workgroups), waves 0..%d:" % (nw - 1))
+    for i, nm in enumerate(["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]):
+        print(f"    {nm:11s}", " ".join(f"{ph[:, w, i].mean():9.0f}" for w in range(nw)), f"  share {ph[:, :, i].sum() / tot.sum():.3f}")
+    print(f"    total      ", " ".join(f"{tot[:, w].mean():9.0f}" for w in range(nw)))
