@@ -125,7 +125,12 @@ struct GemmParams {
     int32_t pixels_per_image;
     // diagnostic builds only (tools/gemm_stamps.py): per-workgroup s_memrealtime stamps, or null
     unsigned long long* stamps;
+    // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
+    // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
+    // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).
+    unsigned* queue;
 };
+constexpr int kGemmQueueWords = 9 * 32;
 
 // dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).
 void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,

@@ -2,6 +2,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "gemm_core.h"
 
@@ -53,29 +56,34 @@ ProfScope::~ProfScope() {
 }
 
 static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w",
-                                  "160x128x64/4w"};
-int gemm_num_configs() { return 5; }
-const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 5 ? kCfgNames[cfg] : "?"; }
+                                  "160x128x64/4w", "256x256x64/8w-pp", "64x64x64/4w-ring6"};
+int gemm_num_configs() { return 7; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 7 ? kCfgNames[cfg] : "?"; }
 
-// Tile choice.  The persistent kernel runs ceil(tiles / resident workgroups) rounds, so the cost of a
+// Tile choice.  The persistent kernels run ceil(tiles / resident workgroups) rounds, so the cost of a
 // configuration is rounds x (tile area) x (workgroups sharing a CU) / (its main-loop efficiency relative
-// to the 256x256 tile, measured at M = 80780 where rounds do not matter: profiles/
+// to the two-group 256x256 kernel, measured at M = 80780 where rounds do not matter: profiles/
 // r01_kernel_microbench_f16.json).  Examples at M = 20195: qkv / fc1 (N = 3072 / 4096) -> 256x256 (4 and
-// 5 rounds); proj / fc2 (N = 1024) -> 160x128: 1016 tiles = 2 rounds of 512, where 128x128 needs 3
-// (fc2 0.201 -> 0.175 ms); the 768^2 256-channel convolutions -> 256x256 (9 rounds exactly).
+// 5 rounds); proj / fc2 (N = 1024) -> 160x128: 1016 tiles = 2 rounds of 512, where 128x128 needs 3 and
+// 256x256 leaves 3/4 of the second round idle; the 256-channel convolutions at 768^2 and 384^2 -> 256x256.
 // The 64x64 tile is for the single-window ViTs (M = 577) and the low-resolution decoder levels.
-static int pick_config(int64_t M, int64_t N) {
+static int pick_config(int64_t M, int64_t N, int64_t K) {
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
-    if (N < 128 || t1 < 256) return 2;
+    if (N < 128 || t1 < 256) {
+        // few 64x64 tiles and a long K (the M = 577 fc2: 160 tiles x 64 slabs): the six-slot ring keeps
+        // five slabs in flight (33 -> 19 us); with many tiles its 96 KiB of LDS per workgroup costs more
+        // in occupancy than the latency it hides
+        return cdiv(M, 64) * cdiv(N, 64) <= 256 && K >= 2048 ? 6 : 2;
+    }
     struct Cand {
         int cfg, bm, bn, per_cu;
         double eff;
     };
-    static const Cand cands[] = {{0, 256, 256, 1, 1.0}, {4, 160, 128, 2, 0.89}, {1, 128, 128, 2, 0.85}};
+    static const Cand cands[] = {{5, 256, 256, 1, 1.0}, {4, 160, 128, 2, 0.80}, {1, 128, 128, 2, 0.76}};
     int best = 1;
     double best_cost = 0.0;
     for (const Cand& c : cands) {
-        if (N < c.bn) continue;
+        if (N < c.bn || (c.cfg == 5 && K < 128)) continue;
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         const int64_t rounds = cdiv(tiles, (int64_t)256 * c.per_cu);
         const double cost = (double)rounds * c.bm * c.bn * c.per_cu / c.eff;
@@ -104,8 +112,30 @@ static void launch_typed(const GemmParams& p, AMode amode, EpiKind epi, int cfg,
     fail(ME_ERR_BAD_ARG, "gemm: unsupported (A-mode %d, epilogue %d)", (int)amode, (int)epi);
 }
 
-void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
+// One tile-queue block per launch stream (kernels of a stream run one after the other; the last
+// workgroup of a launch leaves the counters zeroed for the next).
+static unsigned* queue_for_stream(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, unsigned*> blocks;
+    int dev = 0;
+    ME_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned*& q = blocks[{dev, stream}];
+    if (!q) {
+        ME_HIP(hipMalloc((void**)&q, kGemmQueueWords * sizeof(unsigned)));
+        ME_HIP(hipMemset(q, 0, kGemmQueueWords * sizeof(unsigned)));
+    }
+    return q;
+}
+
+void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg) {
+    GemmParams p = p_in;
+    // Dynamic tile order (TileQueue in gemm_core.h) is an opt-in: measured on the full step it gains 0.4 %
+    // (26.57 vs 26.68 ms) -- the launches the side streams disturb most (proj / fc2) have two tiles per
+    // workgroup, too coarse for a late workgroup to hand work to its neighbours.
+    static const bool dynamic_order = getenv("ME_GEMM_DYNAMIC_TILES") != nullptr;
+    p.queue = dynamic_order ? queue_for_stream(stream) : nullptr;
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
              p.N, p.K);
     ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);
@@ -122,7 +152,9 @@ void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, h
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
-    const int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N);
+    int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K);
+    if (cfg == 5 && p.K < 128) cfg = 0;
+    if (cfg == 6 && p.K < 128) cfg = 4;  // the two-group kernel prefetches two slabs ahead
     static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +

@@ -44,6 +44,33 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The same instruction issued behind the compiler's back (two-group kernel).  The waitcnt pass orders every
+// later LDS access behind a builtin LDS-DMA with vmcnt(0), which would serialise exactly what that kernel
+// overlaps; issued as asm the DMA is invisible to it and the kernel places its own counted waits.  The
+// compiler's own vmcnt waits stay safe: an unknown extra VMEM operation in flight can only make a counted
+// wait longer (returns are in order).  lds_base: wave-uniform LDS byte address; lane l writes base + 16 l.
+// Address = uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no address VALU, half the
+// address registers.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is "reserved": the kernel has no other user of it
+__device__ __forceinline__ void glds16_raw(const void* sbase, unsigned voff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_base)
+                 : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// a pointer the compiler may hold in VGPRs although every lane has the same value -> SGPR pair
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 // Phi(x) * x with the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121).
 // erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), evaluated on |x| so the negative
 // tail keeps its relative accuracy.
@@ -72,6 +99,48 @@ __device__ __forceinline__ void store4_16(void* dst, float a, float b, float c, 
     v[3] = (T)d;
     *reinterpret_cast<v4*>(dst) = v;
 }
+
+// Dynamic tile order of the persistent kernels.  With the static order (workgroup b takes tiles b, b+G,
+// ...) a workgroup that starts late delays the whole launch by its lateness, and beside the side-stream
+// ViTs somebody always starts late: their small kernels take CUs at every kernel boundary (bench.py:
+// 2.3 ms of a 26.7 ms step).  Here every workgroup still starts on tile b, but takes its further tiles
+// from a ticket counter of its XCD (so each XCD keeps walking its own contiguous run of the tile order):
+// a workgroup that lost time simply takes fewer tiles.  A tile must be known one tile ahead (its first
+// slabs are staged under the previous tile's last ones), so tickets are drawn two tiles ahead, always
+// where their latency is already paid: in the prologue behind the first staging loads, and at the start
+// of each epilogue beside the bias loads.  Lane 0 of wave 0 draws; the tile index reaches the other
+// waves through one word of the (then free) epilogue scratch and one extra barrier per tile.  The last
+// workgroup to exit zeroes the counters for the next launch on the stream.  Results do not depend on
+// which workgroup computes a tile.
+struct TileQueue {
+    unsigned* q;
+    int xcd, first_round, ntiles;
+    __device__ __forceinline__ void init(unsigned* queue, int ntiles_) {
+        q = queue, ntiles = ntiles_;
+        xcd = blockIdx.x & 7;
+        first_round = gridDim.x >> 3;  // tickets continue after the static first round
+    }
+    // one lane: next tile of this XCD's run, or -1
+    __device__ __forceinline__ int draw() {
+        const unsigned ticket =
+            __hip_atomic_fetch_add(q + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long vb = xcd + 8ll * ((long long)ticket + first_round);
+        return vb < ntiles ? (int)vb : -1;
+    }
+    __device__ __forceinline__ void leave() {
+        if (threadIdx.x == 0) {
+            const unsigned gone =
+                __hip_atomic_fetch_add(q + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == gridDim.x - 1) {  // everybody else has drawn its last ticket before counting out
+                for (int i = 0; i < 9; ++i)
+                    __hip_atomic_store(q + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
 
 // block -> tile.  Blocks b and b+8 share an XCD (and its 4 MiB L2), so each XCD gets a contiguous run
 // of the tile order; that order walks "super-rows" of 8 tile rows column by column, so the ~32 tiles
@@ -242,13 +311,23 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
 // m = ... + (lane & 15), columns n = ... + 4*(lane >> 4) + r.  Each wave transposes its block through a
 // private LDS region (the main loop's LDS is free by now) so that 8 consecutive lanes own one whole
 // TN-column row segment.
-template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH>
+// PIN_CONSTS (two-group kernel): the per-lane constants are loaded under `n_ok` and used under
+// `row.m < M && n_ok` inside one of several run() instances, so on the (statically possible) paths where
+// a wave stores nothing the waitcnt pass still sees their loads pending and protects the registers with a
+// vmcnt(0) at their next write -- inside the K loop, on every slab.  An unconditional empty asm "use"
+// after the row set-up settles them for good (cost: what is left of one L2 load latency, once per tile).
+// after_loads(): called once the per-lane constant loads have been issued (the tile queue draws its
+// ticket there, beside them)
+template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool PIN_CONSTS = false,
+          typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
-                                              int wm, int wn, int lane, char* epi_lds) {
+                                              int wm, int wn, int lane, char* epi_lds,
+                                              Hook after_loads = Hook()) {
     const int frow = lane & 15;
     const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
     if constexpr (EPI == EPI_HEAD_FINAL) {
         // N <= 32 = the whole tile width (WN == 1): relu(acc + bias) . w2, reduced over n.
+        after_loads();
         float w2v[NI][4], bv[NI][4];
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -309,6 +388,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 if (hi_ok) lc.gamma[1] = *reinterpret_cast<const float4*>(p.gamma + n + 4);
             }
         }
+        after_loads();
         EpiRow row;
         row.m = m0 + wm * TM + r0;
         row.b = row.y = row.x = 0;
@@ -355,6 +435,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
             }
         };
+        if constexpr (PIN_CONSTS) {
+            asm volatile(""
+                         : "+v"(lc.bias[0].x), "+v"(lc.bias[0].y), "+v"(lc.bias[0].z), "+v"(lc.bias[0].w),
+                           "+v"(lc.bias[1].x), "+v"(lc.bias[1].y), "+v"(lc.bias[1].z), "+v"(lc.bias[1].w));
+            asm volatile(""
+                         : "+v"(lc.gamma[0].x), "+v"(lc.gamma[0].y), "+v"(lc.gamma[0].z), "+v"(lc.gamma[0].w),
+                           "+v"(lc.gamma[1].x), "+v"(lc.gamma[1].y), "+v"(lc.gamma[1].z), "+v"(lc.gamma[1].w));
+        }
         if constexpr (EPI == EPI_STORE) {
             const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias;
             if (simple && p.act == ACT_NONE)
@@ -507,7 +595,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     TileSrc cur, nxt;
     setup(cur, vb);
     stage(cur, 0, 0);
+    const bool dyn = p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
+    TileQueue tq;
+    tq.init(p.queue, ntiles);
+    int next_vb = vb + (int)gridDim.x;
+    // second tile: drawn behind the first staging loads, handed over through the still idle buffer 1
+    if (dyn && tid == 0) *reinterpret_cast<int*>(smem + STAGE_BYTES) = tq.draw();
     __syncthreads();
+    if (dyn) {
+        next_vb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + STAGE_BYTES));
+        __syncthreads();
+    }
     int buf = 0;
     [[maybe_unused]] int stamp_i = 0;
 #ifdef ME_GEMM_STAMPS
@@ -534,7 +632,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     ME_STAMP();
 
     while (true) {
-        const bool has_next = vb + (int)gridDim.x < ntiles;
+        const bool has_next = next_vb >= 0 && next_vb < ntiles;
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -546,7 +644,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
             if (kt + 1 < nk) {
                 stage(cur, kt + 1, buf ^ 1);
             } else if (has_next) {
-                setup(nxt, vb + gridDim.x);
+                setup(nxt, next_vb);
                 stage(nxt, 0, buf ^ 1);
             }
             ME_PHASE(0);
@@ -594,9 +692,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
         }
         ME_STAMP();
         // buf now holds the next tile's first slab; buf^1 was consumed last and is the scratch
+        char* scratch0 = smem + (buf ^ 1) * STAGE_BYTES;
+        int drawn = -1;  // lane 0 of wave 0: the tile after next
         gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(
-            p, acc, cur.m0, cur.n0, wm, wn, lane,
-            smem + (buf ^ 1) * STAGE_BYTES + wave * (16 * MI_CH * (TN * 4)));
+            p, acc, cur.m0, cur.n0, wm, wn, lane, scratch0 + wave * (16 * MI_CH * (TN * 4)), [&]() {
+                if (dyn && has_next && tid == 0) drawn = tq.draw();
+            });
         ME_STAMP();
         if (!has_next) {
 #ifdef ME_GEMM_STAMPS
@@ -604,17 +705,366 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
                 for (int i = 0; i < 4; ++i)
                     p.stamps[(size_t)gridDim.x * 16 + ((size_t)blockIdx.x * NW + wave) * 4 + i] = ph[i];
 #endif
+            if (dyn) tq.leave();
             break;
         }
+        if (dyn && tid == 0) *reinterpret_cast<int*>(scratch0) = drawn;  // wave 0's own scratch
         // the scratch is restaged by the next tile's first iteration: its LDS reads must be done
         __syncthreads();
         cur = nxt;
-        vb += gridDim.x;
+        vb = next_vb;
+        if (dyn) {
+            next_vb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(scratch0));
+            __syncthreads();
+        } else {
+            next_vb = vb + (int)gridDim.x;
+        }
     }
 }
 
 #undef ME_STAMP
 #undef ME_PHASE
+
+// ---------------------------------------------------------------------------------------------------
+// Two-group ("ping-pong") form of the 8-wave kernel.
+//
+// Phase accounting of the kernel above (tools/gemm_stamps.py) shows where its time goes: the eight
+// waves issue their LDS-DMA together at the top of a slab, the texture path moves 64 B/clk per CU, so
+// the 64 KiB of a 256x256 slab hold every wave in "issue" for ~0.5 us while the matrix pipe idles; the
+// waves of a SIMD then share the pipe for the MFMAs.  DMA time and MFMA time ADD.  Here the two waves of
+// a SIMD (w and w + 4) take complementary roles instead:
+//   group 0 (waves 0-3) stages the ACTIVATION rows of slab s+1 at the top of slab s, then runs its MFMAs;
+//   group 1 (waves 4-7) runs half of its MFMAs first, stages the WEIGHT rows of slab s+2, then the rest.
+// While one wave of a SIMD is held by the texture path the other owns the matrix pipe.  The weights are
+// requested two slabs ahead, so the later issue point costs no latency at the closing wait; that takes a
+// three-slot ring for the weights beside the two-slot ring of the activations: 2*BM*128 + 3*BN*128 B
+// (160 KiB for the 256x256 tile: all of a CU's LDS).  One barrier per slab as before; group 1 closes a
+// slab with a counted vmcnt (its newest DMA group may stay in flight), group 0 with vmcnt(0).
+// Requires K >= 128.
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    static_assert(WM * WN == 8, "two groups of four waves");
+    static_assert(BM / WM >= BN / WN, "the first k-substep's MI groups prefetch the NI weight fragments");
+    constexpr int HW = 4;  // waves per group
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int W_RING = 2 * A_BYTES;
+    constexpr int A_IT = (BM / 8) / HW, B_IT = (BN / 8) / HW;
+    constexpr int IT = A_IT > B_IT ? A_IT : B_IT;
+    static_assert((BM / 8) % HW == 0 && (BN / 8) % HW == 0, "tile rows must split over a group");
+    constexpr int MI_CH = epi_mi_chunk(MI, TN, HW, A_BYTES < B_BYTES ? A_BYTES : B_BYTES);
+    constexpr int SCR = 16 * MI_CH * (TN * 4);  // epilogue scratch per wave
+    static_assert(HW * SCR <= A_BYTES && HW * SCR <= B_BYTES, "epilogue scratch exceeds a ring slot");
+    typedef typename MfmaOp<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2, gw = wave & 3;  // waves w and w + 4 share a SIMD
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    struct Src {
+        int m0, n0;
+        // this wave's DMA sources, activation rows (group 0) or weight rows (group 1): a uniform base (the
+        // tile's first row) and per-lane 32-bit byte offsets from it -- the kernel has no VGPR to spare
+        // for 64-bit pointers
+        const char* base;
+        unsigned s[IT];
+    };
+    auto pixel_of = [&](int gm) -> int64_t {  // A_CONV: first tap-(0,0)-relative element of output row gm
+        const int ppi = p.out_H * p.out_W;
+        const int b = gm / ppi;
+        const int rem = gm - b * ppi;
+        const int y = rem / p.out_W;
+        const int x = rem - y * p.out_W;
+        return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
+    };
+    auto setup = [&](Src& t, int vb) {
+        tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
+        if (group == 0) {
+            int64_t base_el;  // element offset of the tile's first row (uniform)
+            if constexpr (AMODE == A_PLAIN)
+                base_el = (int64_t)t.m0 * p.lda;
+            else
+                base_el = pixel_of(t.m0) * p.Cin;
+            t.base = (const char*)p.A + base_el * 2;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int row = (i * HW + gw) * 8 + srow;
+                const int chunk = sslot ^ ((row >> 1) & 7);
+                int gm = t.m0 + row;
+                gm = gm < p.M ? gm : p.M - 1;
+                int64_t el;
+                if constexpr (AMODE == A_PLAIN)
+                    el = (int64_t)gm * p.lda;
+                else
+                    el = pixel_of(gm) * p.Cin;
+                t.s[i] = (unsigned)((el - base_el) * 2) + chunk * 16;
+            }
+        } else {
+            t.base = (const char*)p.W + (int64_t)t.n0 * p.K * 2;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int row = (i * HW + gw) * 8 + srow;
+                const int chunk = sslot ^ ((row >> 1) & 7);
+                int gn = t.n0 + row;
+                gn = gn < p.N ? gn : p.N - 1;
+                t.s[i] = (unsigned)((int64_t)(gn - t.n0) * p.K * 2) + chunk * 16;
+            }
+        }
+    };
+
+    const int nk = p.K / 64;
+    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
+    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
+    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
+    auto stage_a_offset = [&](int kt) -> int64_t {
+        if constexpr (AMODE == A_PLAIN) {
+            return (int64_t)kt * 128;
+        } else {
+            if (kt == 0) tap_kc = tap_ky = tap_kx = 0;
+            const int64_t off =
+                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
+            if (++tap_kc == cin_steps) {
+                tap_kc = 0;
+                if (++tap_kx == p.KW) {
+                    tap_kx = 0;
+                    ++tap_ky;
+                }
+            }
+            return off;
+        }
+    };
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    auto stage_T = [&](const Src& t, int kt, int slot) {  // group 0
+        const char* base = uniform_ptr(t.base + stage_a_offset(kt));
+        const unsigned dst = smem_base + slot * A_BYTES + gw * 1024;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
+    };
+    auto stage_W = [&](const Src& t, int kt, int slot) {  // group 1
+        const char* base = uniform_ptr(t.base + (int64_t)kt * 128);
+        const unsigned dst = smem_base + W_RING + slot * B_BYTES + gw * 1024;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
+    };
+
+    const int frow = lane & 15;
+    const int fswz = frow >> 1;
+    const int fslot0 = ((lane >> 4) ^ fswz) * 16;
+    const int fslot1 = (((lane >> 4) + 4) ^ fswz) * 16;
+    const int a_rd = (wm * TM + frow) * 128;
+    const int b_rd = (wn * TN + frow) * 128;
+
+    // The matrix pipe goes to the higher priority, then to the older wave.  Left alone, group 0 (older)
+    // wins it for all 64 of its MFMAs and group 1 reaches its mid-slab DMA only after group 0 has finished
+    // -- the DMA then runs beside nothing (phase accounting: group 1's first k-substep 1610 cycles, group 0
+    // 1170 cycles at the barrier).  With static priority group 1 computes first, and its DMA issue falls
+    // into the time group 0 still has MFMAs to run.
+    if (group == 1) __builtin_amdgcn_s_setprio(1);
+    int vb = blockIdx.x;
+    Src cur, nxt;
+    setup(cur, vb);
+    const bool dyn = p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
+    TileQueue tq;
+    tq.init(p.queue, ntiles);
+    int next_vb = vb + (int)gridDim.x;
+    if (group == 0) {
+        stage_T(cur, 0, 0);
+        // second tile: drawn behind the first staging loads, handed over through the still empty third
+        // weight slot (its first DMA comes mid-slab 0, after the extra barrier below)
+        if (dyn && tid == 0) *reinterpret_cast<int*>(smem + W_RING + 2 * B_BYTES) = tq.draw();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        stage_W(cur, 0, 0);
+        stage_W(cur, 1, 1);
+        if constexpr (B_IT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (B_IT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (dyn) {
+        next_vb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + W_RING + 2 * B_BYTES));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    int ts = 0, ws = 0;  // ring slots of the slab being consumed
+    [[maybe_unused]] int stamp_i = 0;
+#ifdef ME_GEMM_STAMPS
+#define ME_STAMP()                                                                       \
+    do {                                                                                 \
+        if (p.stamps && tid == 0 && stamp_i < 16)                                        \
+            p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    // [0] top-of-slab DMA issue (group 0), [1] first k-substep, [2] mid-slab DMA issue (group 1),
+    // [3] second k-substep, [4] closing vmcnt wait, [5] barrier
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+#define ME_PHASE(i)                                                 \
+    do {                                                            \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                          \
+        if ((i) >= 0) ph[(i) < 0 ? 0 : (i)] += t_ - pt;             \
+        pt = t_;                                                    \
+    } while (0)
+#else
+#define ME_STAMP() do {} while (0)
+#define ME_PHASE(i) do {} while (0)
+#endif
+    ME_STAMP();
+
+    while (true) {
+        const bool has_next = next_vb >= 0 && next_vb < ntiles;
+        if (has_next) setup(nxt, next_vb);
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            ME_PHASE(-1);
+            if (group == 0) {
+                if (kt + 1 < nk)
+                    stage_T(cur, kt + 1, ts ^ 1);
+                else if (has_next)
+                    stage_T(nxt, 0, ts ^ 1);
+            }
+            ME_PHASE(0);
+            const char* sa = smem + ts * A_BYTES + a_rd;
+            const char* sw = smem + W_RING + ws * B_BYTES + b_rd;
+            constexpr int G = 2 * MI;
+            frag af[G], wf[2][NI];
+            auto rd_a = [&](int g) {
+                return *reinterpret_cast<const frag*>(sa + (g % MI) * 2048 + (g < MI ? fslot0 : fslot1));
+            };
+            auto rd_w = [&](int kk, int j) {
+                return *reinterpret_cast<const frag*>(sw + j * 2048 + (kk == 0 ? fslot0 : fslot1));
+            };
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
+            af[0] = rd_a(0);
+            af[1] = rd_a(1);
+            // first k-substep
+#pragma unroll
+            for (int g = 0; g < MI; ++g) {
+                if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+                if (g < NI) wf[1][g] = rd_w(1, g);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[g % MI][j] = MfmaOp<T>::run(wf[0][j], af[g], acc[g % MI][j]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NI + 2, 0);
+            SchedPin<MI, NI, 0>::template run<0>();
+            ME_PHASE(1);
+            bool newer = false;  // group 1: a DMA group younger than the one the next slab needs
+            if (group == 1) {
+                const int w2 = ws == 0 ? 2 : ws - 1;  // (ws + 2) % 3
+                if (kt + 2 < nk) {
+                    stage_W(cur, kt + 2, w2);
+                    newer = true;
+                } else if (has_next) {
+                    stage_W(nxt, kt + 2 - nk, w2);
+                    newer = true;
+                }
+            }
+            ME_PHASE(2);
+            // second k-substep
+#pragma unroll
+            for (int g = MI; g < G; ++g) {
+                if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+                if (g < NI) wf[1][g] = rd_w(1, g);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[g % MI][j] = MfmaOp<T>::run(wf[1][j], af[g], acc[g % MI][j]);
+            }
+            SchedPin<MI, NI, 0>::template run<0>();
+            ME_PHASE(3);
+            if (newer) {
+                if constexpr (B_IT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (B_IT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ME_PHASE(4);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            ME_PHASE(5);
+            ts ^= 1;
+            ws = ws == 2 ? 0 : ws + 1;
+        }
+        ME_STAMP();
+        // ts / ws now name the next tile's first slab; the slots consumed last are the scratch
+        char* scratch0 = smem + (ts ^ 1) * A_BYTES;  // group 0's region; its first word doubles as hand-off
+        int drawn = -1;                              // lane 0 of wave 0: the tile after next
+        {
+            const int wprev = ws == 0 ? 2 : ws - 1;
+            char* scr = (group == 0 ? scratch0 : smem + W_RING + wprev * B_BYTES) + gw * SCR;
+            gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, scr, [&]() {
+                if (dyn && has_next && tid == 0) drawn = tq.draw();
+            });
+        }
+        ME_STAMP();
+        if (!has_next) {
+#ifdef ME_GEMM_STAMPS
+            if (p.stamps && lane == 0)
+                for (int i = 0; i < 6; ++i)
+                    p.stamps[(size_t)gridDim.x * 16 + ((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif
+            if (dyn) tq.leave();
+            break;
+        }
+        if (dyn && tid == 0) *reinterpret_cast<int*>(scratch0) = drawn;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the scratch slots are restaged by the next tile's first slab
+        asm volatile("" ::: "memory");
+        cur = nxt;
+        vb = next_vb;
+        if (dyn) {
+            next_vb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(scratch0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everyone has read the word before slab 0 restages the slot
+            asm volatile("" ::: "memory");
+        } else {
+            next_vb = vb + (int)gridDim.x;
+        }
+    }
+}
+#undef ME_STAMP
+#undef ME_PHASE
+
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = (2 * BM + 3 * BN) * 128;
+    ME_CHECK(p.K >= 128, ME_ERR_BAD_SHAPE, "gemm: the two-group kernel needs K >= 128 (K = %d)", p.K);
+    auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
+    static int resident = 0;
+    if (!resident) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int per_cu = 0, dev = 0, cus = 0;
+        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, smem));
+        ME_HIP(hipGetDevice(&dev));
+        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        per_cu = per_cu < 1 ? 1 : per_cu;
+        resident = per_cu * cus;
+        resident -= resident % 8;
+        resident = resident < 8 ? 8 : resident;
+    }
+    const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
+             (long long)ntiles);
+    const int64_t grid = ntiles < resident ? ntiles : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+    ME_HIP(hipGetLastError());
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
@@ -642,6 +1092,198 @@ void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     ME_HIP(hipGetLastError());
 }
 
+// s_waitcnt vmcnt(N) with a compile-time N (gfx9 encoding: vmcnt in bits 3:0 and 15:14)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// vmcnt(rem * P) for a run-time rem in [0, R]
+template <int R, int P>
+struct WaitSlabs {
+    static __device__ __forceinline__ void run(int rem) {
+        if (rem >= R)
+            wait_vmcnt<R * P>();
+        else
+            WaitSlabs<R - 1, P>::run(rem);
+    }
+};
+template <int P>
+struct WaitSlabs<0, P> {
+    static __device__ __forceinline__ void run(int) { wait_vmcnt<0>(); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Deep-ring form for problems that cannot fill the chip (the single-window ViTs: M = 577; the
+// low-resolution decoder levels).  One tile per workgroup; with a 64x64 tile a slab is only 8 MFMAs per
+// wave, so the two-buffer kernel above spends every slab waiting out one full LDS-DMA latency (0.8 us per
+// slab: 51 us for the M = 577 fc2).  Here NST ring slots keep NST-1 slabs in flight behind counted
+// vmcnt waits; one barrier per slab publishes the landed slab and frees the slot consumed before it.
+template <typename T, int BM, int BN, int WM, int WN, int NST, int AMODE, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_IT = (BM / 8) / NW, B_IT = (BN / 8) / NW;
+    constexpr int P = A_IT + B_IT;  // LDS-DMA instructions per wave per slab
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split over waves");
+    static_assert(NST >= 3 && (NST - 2) * P <= 63, "ring depth vs the 6-bit vmcnt");
+    constexpr int MI_CH = epi_mi_chunk(MI, TN, NW, NST * STAGE_BYTES);
+    typedef typename MfmaOp<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    int m0, n0;
+    tile_origin<BM, BN>(p, blockIdx.x, ntiles, m0, n0);
+
+    // DMA sources: uniform base of the tile's first row + per-lane 32-bit byte offsets
+    const int srow = lane >> 3, sslot = lane & 7;
+    auto pixel_of = [&](int gm) -> int64_t {
+        const int ppi = p.out_H * p.out_W;
+        const int b = gm / ppi;
+        const int rem = gm - b * ppi;
+        const int y = rem / p.out_W;
+        const int x = rem - y * p.out_W;
+        return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
+    };
+    int64_t a_base_el;
+    if constexpr (AMODE == A_PLAIN)
+        a_base_el = (int64_t)m0 * p.lda;
+    else
+        a_base_el = pixel_of(m0) * p.Cin;
+    const char* a_base = (const char*)p.A + a_base_el * 2;
+    const char* w_base = (const char*)p.W + (int64_t)n0 * p.K * 2;
+    unsigned a_off[A_IT], w_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = (i * NW + wave) * 8 + srow;
+        const int chunk = sslot ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int64_t el;
+        if constexpr (AMODE == A_PLAIN)
+            el = (int64_t)gm * p.lda;
+        else
+            el = pixel_of(gm) * p.Cin;
+        a_off[i] = (unsigned)((el - a_base_el) * 2) + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = (i * NW + wave) * 8 + srow;
+        const int chunk = sslot ^ ((row >> 1) & 7);
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_off[i] = (unsigned)((int64_t)(gn - n0) * p.K * 2) + chunk * 16;
+    }
+
+    const int nk = p.K / 64;
+    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
+    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
+    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
+    auto stage_a_offset = [&](int kt) -> int64_t {  // slabs are staged in order
+        if constexpr (AMODE == A_PLAIN) {
+            return (int64_t)kt * 128;
+        } else {
+            const int64_t off =
+                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
+            if (++tap_kc == cin_steps) {
+                tap_kc = 0;
+                if (++tap_kx == p.KW) {
+                    tap_kx = 0;
+                    ++tap_ky;
+                }
+            }
+            return off;
+        }
+    };
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    auto stage = [&](int kt, int slot) {
+        const char* ab = uniform_ptr(a_base + stage_a_offset(kt));
+        const char* wb = uniform_ptr(w_base + (int64_t)kt * 128);
+        const unsigned dst = smem_base + slot * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16_raw(ab, a_off[i], dst + i * (NW * 1024));
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16_raw(wb, w_off[i], dst + A_BYTES + i * (NW * 1024));
+    };
+
+    const int frow = lane & 15;
+    const int fswz = frow >> 1;
+    const int fslot0 = ((lane >> 4) ^ fswz) * 16;
+    const int fslot1 = (((lane >> 4) + 4) ^ fswz) * 16;
+    const int a_rd = (wm * TM + frow) * 128;
+    const int b_rd = A_BYTES + (wn * TN + frow) * 128;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s);
+
+    int slot = 0, fill = NST - 1;  // slot being consumed; slot the next staged slab goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        // slabs kt+1 .. min(kt+NST-2, nk-1) may stay in flight
+        WaitSlabs<NST - 2, P>::run(nk - 1 - kt);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST - 1 < nk) stage(kt + NST - 1, fill);
+        const char* sb = smem + slot * STAGE_BYTES;
+        {
+            constexpr int G = 2 * MI;
+            frag af[G], wf[2][NI];
+            auto rd_a = [&](int g) {
+                return *reinterpret_cast<const frag*>(sb + a_rd + (g % MI) * 2048 + (g < MI ? fslot0 : fslot1));
+            };
+            auto rd_w = [&](int kk, int j) {
+                return *reinterpret_cast<const frag*>(sb + b_rd + j * 2048 + (kk == 0 ? fslot0 : fslot1));
+            };
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[1][j] = rd_w(1, j);
+#pragma unroll
+            for (int g = 0; g < G; ++g) af[g] = rd_a(g);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[g % MI][j] = MfmaOp<T>::run(wf[g < MI ? 0 : 1][j], af[g], acc[g % MI][j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the next barrier
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        fill = fill + 1 == NST ? 0 : fill + 1;
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring: it becomes the epilogue scratch
+    asm volatile("" ::: "memory");
+    gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(p, acc, m0, n0, wm, wn, lane,
+                                                 smem + wave * (16 * MI_CH * (TN * 4)));
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, int AMODE, int EPI>
+void gemm_launch_ring(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = NST * (BM + BN) * 128;
+    auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, NST, AMODE, EPI>;
+    static bool configured = false;
+    if (!configured) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        configured = true;
+    }
+    const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
+             (long long)ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(WM * WN * 64), smem, stream, p);
+    ME_HIP(hipGetLastError());
+}
+
 // One instantiation set per (dtype, amode, epi); defined in gemm_*.hip.
 template <typename T, int AMODE, int EPI>
 void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
@@ -655,6 +1297,8 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 256, 128, 4, 2, AMODE, EPI>(p, stream); break;     \
             case 4: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
+            case 5: gemm_launch_pp<T, 256, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
+            case 6: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

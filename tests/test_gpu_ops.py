@@ -22,7 +22,7 @@ def _check(ctx, rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, -1])
 @pytest.mark.parametrize("shape", [(577, 256, 128), (1000, 132, 192), (2309, 384, 256), (5000, 512, 64)])
 def test_linear(dtype, cfg, shape):
     M, N, K = shape
@@ -56,8 +56,42 @@ def test_linear_gelu(dtype):
     assert float((out32.double() - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 4, 5])
+@pytest.mark.parametrize("shape", [(20195, 1024, 256), (9000, 2304, 192), (70000, 256, 128)])
+def test_linear_persistent_rounds(cfg, shape):
+    """more tiles than resident workgroups: every workgroup walks several tiles, the K stream crosses tile
+    boundaries (and, in the two-group kernel, the weight ring runs two slabs ahead across them)"""
+    M, N, K = shape
+    ctx = ctx_for("tiny", "f16")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = dev16(torch.randn(M, K, generator=g), "f16")
+    w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), "f16")
+    bias = torch.randn(N, generator=g).cuda()
+    out32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), None, ptr(out32), 0, cfg))
+    ctx.synchronize()
+    ref = a.float() @ w.float().T + bias
+    assert float((out32 - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    again = torch.empty_like(out32)
+    _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), None, ptr(again), 0, cfg))
+    ctx.synchronize()
+    assert torch.equal(out32, again)
+
+
+def test_dynamic_tile_order_in_a_child_process():
+    """ME_GEMM_DYNAMIC_TILES is read once per process: run the multi-round cases again with it set"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ME_GEMM_DYNAMIC_TILES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu",
+                        "-k", "persistent_rounds or conv2d"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 def test_linear_residual(dtype, cfg):
     M, N, K = 1154, 256, 512
     ctx = ctx_for("tiny", dtype)
@@ -137,7 +171,7 @@ def test_layernorm(dtype, dim):
     dict(B=1, H=12, W=12, Cin=64, Cout=32, k=3, stride=2),
     dict(B=1, H=20, W=20, Cin=128, Cout=64, k=1, stride=1),
 ])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_conv2d(dtype, case, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout, k, s = (case[n] for n in ("B", "H", "W", "Cin", "Cout", "k", "stride"))
@@ -172,7 +206,7 @@ def test_conv2d(dtype, case, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_conv_transpose(dtype, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout = 2, 18, 18, 128, 64

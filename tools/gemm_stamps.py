@@ -9,10 +9,10 @@ ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 lib.me_debug_set_stamps.argtypes = [C.c_void_p]
 M = 35 * 577
-for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 1), (4096, 1024, "fc1", 0)]:
+for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (3072, 1024, "qkv", 5), (1024, 4096, "fc2", 4), (4096, 1024, "fc1", 5)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     bias = torch.randn(N, device="cuda"); out16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
-    stamps = torch.zeros(2048 * 16, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
     for it in range(3):
         stamps.zero_()
         lib.me_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
@@ -22,14 +22,16 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 1), (4096,
     lib.me_debug_set_stamps(None)
     raw = stamps.cpu().numpy()
     s = raw.reshape(-1, 16).astype(np.float64)
-    nwg = int(np.sum(s[:256, 0] > 0)) if cfg == 0 else int(np.sum(s[:512, 0] > 0))
-    nw = 8 if cfg in (0, 3) else 4
-    ph = raw[nwg * 16: nwg * 16 + nwg * nw * 4].reshape(nwg, nw, 4).astype(np.float64)
+    nwg = int(np.sum(s[:256, 0] > 0)) if cfg in (0, 5) else int(np.sum(s[:512, 0] > 0))
+    nw = 8 if cfg in (0, 3, 5) else 4
+    npz = 8 if cfg == 5 else 4
+    ph = raw[nwg * 16: nwg * 16 + nwg * nw * npz].reshape(nwg, nw, npz).astype(np.float64)
+    names = ["dma top", "k-substep 0", "dma mid", "k-substep 1", "vmcnt", "barrier"] if cfg == 5 else ["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]
     s = s[:nwg]
     t0 = s[:, 0].min()
     us = (s - t0) / 100.0   # 100 MHz
     us[s == 0] = np.nan
-    print(name, "workgroups", len(s), "kernel span us", np.nanmax(us))
+    print(name, "cfg", cfg, "workgroups", len(s), "kernel span us", np.nanmax(us))
     # stamps: 0 start, then per tile (main_end, epi_end)
     for t in range(5):
         me, ee = 1 + 2 * t, 2 + 2 * t
@@ -39,6 +41,6 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 1), (4096,
               f"  epilogue {np.nanmean(us[:, ee] - us[:, me]):.2f} us (min {np.nanmin(us[:, ee] - us[:, me]):.2f} max {np.nanmax(us[:, ee] - us[:, me]):.2f})  start spread {np.nanstd(prev):.2f}")
     tot = ph.sum(axis=2)
     print("  phase cycles per wave (mean over workgroups), waves 0..%d:" % (nw - 1))
-    for i, nm in enumerate(["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]):
+    for i, nm in enumerate(names):
         print(f"    {nm:11s}", " ".join(f"{ph[:, w, i].mean():9.0f}" for w in range(nw)), f"  share {ph[:, :, i].sum() / tot.sum():.3f}")
     print(f"    total      ", " ".join(f"{tot[:, w].mean():9.0f}" for w in range(nw)))
