@@ -33,19 +33,22 @@ HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_gemm.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of
-    tools/gemm_probe.py on the qkv and fc1 shapes, the two shapes this kernel alternates between in the
-    step).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced
-    stream (MI355X_MICROARCH.md, HBM), so it is doubled.  None for any other kernel."""
-    if kernel_name != "gemm_kernel<f16,256x256x64/8w,plain,store>":
-        return None
+    """(HBM-side bytes per launch, algorithmic bytes per launch, MFMA utilisation) of the dominant kernel
+    from the committed rocprofv3 PMC passes (profiles/r01_pmc_kernels.json, written by
+    tools/pmc_collect.py: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/gemm_probe.py on
+    the shapes this kernel alternates between in the step).  Both counters are in KiB; on gfx950
+    FETCH_SIZE reports half of the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM), so it is
+    doubled; Infinity-Cache hits are included in it.  (None, None, None) for a kernel without a pass."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
-        per = [(2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0 for k in ("qkv", "fc1")]
-        return sum(per) / len(per)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")))
+        ops = [v for v in pmc.values() if v.get("bench_kernel") == kernel_name]
+        if not ops:
+            return None, None, None
+        n = float(len(ops))
+        return (sum(v["hbm_bytes"] for v in ops) / n, sum(v["algorithmic_bytes"] for v in ops) / n,
+                sum(v["mfma_util"] for v in ops) / n)
     except Exception:
-        return None
+        return None, None, None
 
 
 def parse_args():
@@ -188,6 +191,7 @@ def main():
         dom = max(prof, key=lambda k: k["total_ms"])
         prof_ms = sum(k["total_ms"] for k in prof)
         dom_ms = dom["total_ms"] / dom["launches"]
+        traffic, alg_bytes, mfma_util = pmc_traffic(dom["kernel"])
         achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3) / 1e12
         step_ms = elapsed / args.steps * 1e3
         kernels = sorted(prof, key=lambda k: -k["total_ms"])
@@ -227,10 +231,9 @@ def main():
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(dom["kernel"]),
-                "algorithmic_bytes": (None if dom["kernel"] != "gemm_kernel<f16,256x256x64/8w,plain,store>"
-                                      else 0.5 * ((20195 * 1024 + 3072 * 1024 + 20195 * 3072) * 2 +
-                                                  (20195 * 1024 + 4096 * 1024 + 20195 * 4096) * 2)),
+                "traffic": traffic,
+                "algorithmic_bytes": alg_bytes,
+                "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 3),
                 "share_of_profiled_kernel_time": round(dom["total_ms"] / prof_ms, 3),
                 "whole_step_frac": round(value / world * tflop_img / MFMA_PEAK_TFLOPS, 4),
             },

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Collects rocprofv3 PMC counters for the dominant kernels, one counter group per pass (TCC can hold
+FETCH_SIZE or WRITE_SIZE, not both; SQ groups kept small), on tools/gemm_probe.py runs of one shape each.
+
+    python3 tools/pmc_collect.py out.json [op:cfg ...]
+
+Must be started on the GPU box from a process that has not touched the GPU (this one only spawns
+children).  Output: per op the per-dispatch average of every counter, the kernel's average duration
+under the profiler and the derived figures bench.py / DESIGN.md quote:
+  hbm_bytes   = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE reads half of a wide stream)
+  mfma_util   = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
+                (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs; MFMA_BUSY is 16 cycles per 16x16x32 MFMA)
+  clock_ghz   = GRBM_GUI_ACTIVE / 8 / duration
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
+          ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
+DEFAULT = ["qkv:5", "fc1:5", "proj:4", "fc2:4", "conv768:5", "attn:0"]
+KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_ring_kernel", "attention_kernel")
+
+
+def run_pass(op, cfg, counters, work):
+    out = os.path.join(work, f"{op}_{'_'.join(counters)}"[:80])
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
+           "--", "python3", os.path.join(ROOT, "tools", "gemm_probe.py"), op, str(cfg), "6"]
+    subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    vals, durs = {}, []
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Kernel_Name"] for k in KERNEL_KEYS):
+                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Kernel_Name"] for k in KERNEL_KEYS):
+                durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    # rocprofv3 reports one row per (dispatch, counter); drop the first (cold) dispatch
+    res = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in vals.items()}
+    dur = sum(durs[1:]) / max(1, len(durs) - 1) if durs else None
+    return res, dur
+
+
+def main():
+    out_json = sys.argv[1]
+    ops = sys.argv[2:] or DEFAULT
+    work = os.path.join(ROOT, "gpurun_out", "pmc")
+    os.makedirs(work, exist_ok=True)
+    result = {}
+    for spec in ops:
+        op, cfg = spec.split(":")
+        entry, durs = {}, []
+        for counters in PASSES:
+            vals, dur = run_pass(op, int(cfg), counters, work)
+            entry.update(vals)
+            if dur:
+                durs.append(dur)
+            print(spec, counters, vals, dur, flush=True)
+        entry["duration_us_under_pmc"] = sum(durs) / max(1, len(durs))
+        if "FETCH_SIZE" in entry and "WRITE_SIZE" in entry:
+            entry["hbm_bytes"] = (2.0 * entry["FETCH_SIZE"] + entry["WRITE_SIZE"]) * 1024.0
+        if entry.get("GRBM_GUI_ACTIVE"):
+            gui = entry["GRBM_GUI_ACTIVE"] / 8.0
+            entry["mfma_util"] = entry.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0)
+            entry["clock_ghz"] = gui / entry["duration_us_under_pmc"] / 1e3
+        entry["tile_config"] = int(cfg)
+        result[op] = entry
+    json.dump(result, open(out_json, "w"), indent=1)
+    print(json.dumps(result, indent=1))
+
+
+if __name__ == "__main__":
+    main()
