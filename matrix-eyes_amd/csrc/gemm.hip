@@ -67,6 +67,11 @@ const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 7 ? kCfgNames[c
 // 5 rounds); proj / fc2 (N = 1024) -> 160x128: 1016 tiles = 2 rounds of 512, where 128x128 needs 3 and
 // 256x256 leaves 3/4 of the second round idle; the 256-channel convolutions at 768^2 and 384^2 -> 256x256.
 // The 64x64 tile is for the single-window ViTs (M = 577) and the low-resolution decoder levels.
+static bool dynamic_tile_order() {
+    static const bool on = getenv("ME_GEMM_DYNAMIC_TILES") != nullptr;
+    return on;
+}
+
 static int pick_config(int64_t M, int64_t N, int64_t K) {
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
     if (N < 128 || t1 < 256) {
@@ -85,8 +90,12 @@ static int pick_config(int64_t M, int64_t N, int64_t K) {
     for (const Cand& c : cands) {
         if (N < c.bn || (c.cfg == 5 && K < 128)) continue;
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
-        const int64_t rounds = cdiv(tiles, (int64_t)256 * c.per_cu);
-        const double cost = (double)rounds * c.bm * c.bn * c.per_cu / c.eff;
+        // static order: whole rounds; dynamic order: workgroups draw tiles until none are left, so the
+        // launch takes the average share plus about half a tile of tail
+        const double rounds = dynamic_tile_order() && tiles > 256 * c.per_cu
+                                  ? (double)tiles / (256.0 * c.per_cu) + 0.5
+                                  : (double)cdiv(tiles, (int64_t)256 * c.per_cu);
+        const double cost = rounds * c.bm * c.bn * c.per_cu / c.eff;
         if (best_cost == 0.0 || cost < best_cost) best = c.cfg, best_cost = cost;
     }
     return best;
@@ -134,8 +143,7 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     // Dynamic tile order (TileQueue in gemm_core.h) is an opt-in: measured on the full step it gains 0.4 %
     // (26.57 vs 26.68 ms) -- the launches the side streams disturb most (proj / fc2) have two tiles per
     // workgroup, too coarse for a late workgroup to hand work to its neighbours.
-    static const bool dynamic_order = getenv("ME_GEMM_DYNAMIC_TILES") != nullptr;
-    p.queue = dynamic_order ? queue_for_stream(stream) : nullptr;
+    p.queue = dynamic_tile_order() ? queue_for_stream(stream) : nullptr;
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
              p.N, p.K);
     ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);
