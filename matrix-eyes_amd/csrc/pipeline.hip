@@ -246,8 +246,10 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
         void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
         patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
         void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
+#ifdef ME_DEBUG_HOOKS  // timing experiment only (results are garbage): the step without the side ViTs
         if (!getenv("ME_DEBUG_SKIP_SIDE"))
-        vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s1);
+#endif
+            vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s1);
         merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s1);
         ME_HIP(hipEventRecord(ctx->ev_img, s1));
     }
@@ -418,8 +420,10 @@ void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s) {
     void* patches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
     patchify_windows_launch(x2, patches, B, g, ctx->dtype, s);
     void* tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
+#ifdef ME_DEBUG_HOOKS
     if (!getenv("ME_DEBUG_SKIP_SIDE"))
-    vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
+#endif
+        vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
     float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
     linear(ctx, tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
            dec / 2, ACT_NONE, s);
