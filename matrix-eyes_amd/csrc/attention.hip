@@ -4,8 +4,9 @@
 // SURVEY §3.2) never leaves registers.
 //
 // One workgroup = 4 waves = 128 query rows of one (window, head); each wave owns 32 queries.
-// K/V tiles of 64 keys go global -> registers -> LDS (issue early, write late, double
-// buffered).  Per tile and wave:
+// K/V tiles of 64 keys go global -> LDS by LDS-DMA into a three-slot ring, two tiles ahead of the
+// one being consumed: with one tile of distance (registers, double buffered) every tile waited out a
+// global-load latency -- 1.6 us per tile for a lone workgroup, whatever it computed.  Per tile and wave:
 //   S^T[key][q] = K[key][:] . Q[q][:]          8 x v_mfma_f32_32x32x16 (K tile = A operand)
 //   online softmax with the key index in registers and the query on the lane, so row max/sum
 //   are in-lane plus one cross-half exchange
@@ -45,20 +46,29 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
 
 constexpr int KT = 64;            // keys per LDS tile
 constexpr int TILE_BYTES = KT * 128;
+constexpr int NSLOT = 3;           // LDS ring slots (K + V tile each)
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int tokens, int heads,
-                                                        float scale_log2e) {
+                                                        int ngroups, float scale_log2e) {
     typedef typename Mfma32<T>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int C = heads * 64;
     const int ldq = 3 * C;
-    const int head = blockIdx.y, win = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // Block -> (window, head, query block).  Blocks b and b + 8 share an XCD and its L2: all query blocks of
+    // one (window, head) are given to ONE XCD, so its K and V (148 KB at 577 tokens, read by every query
+    // block) cross the fabric once (3-5 % over the plain x-fastest grid at 35 to 140 windows).
+    const int nqb = (tokens + 127) >> 7;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const int group = xcd + 8 * (slot0 / nqb);  // = win * heads + head
+    const int qblk = slot0 - (slot0 / nqb) * nqb;
+    if (group >= ngroups) return;               // uniform: the whole workgroup leaves before any barrier
+    const int win = group / heads, head = group - win * heads;
+    const int q0 = qblk * 128 + wave * 32;
     const int64_t row0 = (int64_t)win * tokens;
     const T* qbase = qkv + head * 64;
     const T* kbase = qkv + C + head * 64;
@@ -72,38 +82,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         const T* qp = qbase + (row0 + q) * ldq + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+        // settle these loads here: left pending into the loop, the compiler's wait for them sits at the
+        // first MFMA of EVERY tile and, returns being in order, waits for the ring's DMA as well
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 t = __builtin_bit_cast(i32x4, qf[s]);
+            asm volatile("" : "+v"(t));
+            qf[s] = __builtin_bit_cast(frag, t);
+        }
     }
 
-    // K/V staging: thread owns chunks id = tid and tid + 256 of the 64 x 8 chunk tile
-    const int ld_row0 = tid >> 3, ld_c = tid & 7;  // rows ld_row0 and ld_row0 + 32
-    // (named registers, not arrays behind a lambda: those end up in scratch)
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    const int64_t ld_coff = ld_c * 8;
-#define ME_ATT_LOAD_TILE(kt_)                                                  \
-    do {                                                                       \
-        int key0_ = (kt_) * KT + ld_row0, key1_ = key0_ + 32;                  \
-        key0_ = key0_ < tokens ? key0_ : tokens - 1;                           \
-        key1_ = key1_ < tokens ? key1_ : tokens - 1;                           \
-        const int64_t off0_ = (row0 + key0_) * ldq + ld_coff;                  \
-        const int64_t off1_ = (row0 + key1_) * ldq + ld_coff;                  \
-        kreg0 = *reinterpret_cast<const uint4*>(kbase + off0_);                \
-        kreg1 = *reinterpret_cast<const uint4*>(kbase + off1_);                \
-        vreg0 = *reinterpret_cast<const uint4*>(vbase + off0_);                \
-        vreg1 = *reinterpret_cast<const uint4*>(vbase + off1_);                \
-    } while (0)
-    const int wr_k0 = ld_row0 * 128 + ((ld_c ^ ((ld_row0 >> 1) & 7)) << 4);
-    const int wr_k1 = wr_k0 + 32 * 128;  // (row + 32) has the same swizzle bits
-    const int wr_v0 = ld_row0 * 128 + ((ld_c ^ (((ld_row0 >> 1) & 1) << 2)) << 4);
-    const int wr_v1 = wr_v0 + 32 * 128;
-#define ME_ATT_WRITE_TILE(buf_)                                                \
-    do {                                                                       \
-        char* kb_ = smem + (buf_) * TILE_BYTES;                                \
-        char* vb_ = smem + (2 + (buf_)) * TILE_BYTES;                          \
-        *reinterpret_cast<uint4*>(kb_ + wr_k0) = kreg0;                        \
-        *reinterpret_cast<uint4*>(kb_ + wr_k1) = kreg1;                        \
-        *reinterpret_cast<uint4*>(vb_ + wr_v0) = vreg0;                        \
-        *reinterpret_cast<uint4*>(vb_ + wr_v1) = vreg1;                        \
-    } while (0)
+    // K/V staging by LDS-DMA: a wave-instruction moves 8 rows x 128 B (lane -> row lane / 8, 16-byte chunk
+    // lane % 8); the LDS image is linear in the lane, so the swizzle goes on the SOURCE chunk: the LDS slot
+    // (lane % 8) of row rr holds chunk (lane % 8) ^ swz(rr).  Wave w stages pieces 2w and 2w + 1 of K and V.
+    const int st_row = lane >> 3, st_slot = lane & 7;
+    unsigned koff[2], voff[2];
+    auto stage_offsets = [&](int kt) {  // per tile only because the last tile clamps its rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = (2 * wave + i) * 8 + st_row;
+            int key = kt * KT + rr;
+            key = key < tokens ? key : tokens - 1;
+            const unsigned rowb = (unsigned)key * (unsigned)ldq * 2u;  // bytes from the window's first row
+            koff[i] = rowb + ((st_slot ^ ((rr >> 1) & 7)) << 4);
+            voff[i] = rowb + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4);
+        }
+    };
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    const char* kwin = uniform_ptr((const char*)(kbase + row0 * ldq));
+    const char* vwin = uniform_ptr((const char*)(vbase + row0 * ldq));
+    auto stage = [&](int slot) {  // 4 LDS-DMA instructions per wave and tile
+        const unsigned dst = smem_base + slot * (2 * TILE_BYTES) + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16_raw(kwin, koff[i], dst + i * 1024);
+            glds16_raw(vwin, voff[i], dst + TILE_BYTES + i * 1024);
+        }
+    };
 
     // K fragment read: row = ks*32 + r, chunk 2s + h, slot = chunk ^ ((r >> 1) & 7)
     const int k_rd = r * 128;
@@ -120,20 +136,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     float m_run = -1e30f, l_run = 0.f;
 
     const int nkt = (tokens + KT - 1) / KT;
-    ME_ATT_LOAD_TILE(0);
-    ME_ATT_WRITE_TILE(0);
-    __syncthreads();
+    stage_offsets(0);
+    stage(0);
+    if (nkt > 1) {
+        stage_offsets(1);
+        stage(1);
+    }
 
     // One KV tile.  TAIL (last tile only) masks the keys past the end.  Softmax runs on raw scores:
     // p = exp2(s*c - m*c) with c = scale*log2(e) folded into one FMA; O and l are rescaled only in the
     // tiles where some lane's running max actually grows (exact, and rare after the first tiles).
+    // TAIL (last tile) masks the keys past the end.  A wave whose 32 queries all lie past the end (the
+    // last query block of 577 tokens has two such waves' worth) only helps with the staging.
+    // Ring protocol per tile kt: wait for this wave's pieces of tile kt (those of tile kt+1 may stay in
+    // flight), barrier (everybody's pieces have landed; everybody is done with tile kt-1), restage the slot
+    // of tile kt-1 with tile kt+2, compute.
+    const bool active = q0 < tokens;
+    int slot = 0, fill = 2;
     auto tile = [&](int kt, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        const int buf = kt & 1;
-        if (!TAIL) ME_ATT_LOAD_TILE(kt + 1);
-        const char* kb = smem + buf * TILE_BYTES;
-        const char* vb = smem + (2 + buf) * TILE_BYTES;
+        if (kt + 1 < nkt)
+            wait_vmcnt<4>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nkt) {
+            stage_offsets(kt + 2);
+            stage(fill);
+        }
+        const char* kb = smem + slot * (2 * TILE_BYTES);
+        const char* vb = kb + TILE_BYTES;
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        fill = fill == NSLOT - 1 ? 0 : fill + 1;
 
+        if (active) {
         // ---- S^T = K Q^T for the two 32-key halves of the tile
         f32x16 s[2];
 #pragma unroll
@@ -208,12 +245,49 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                     o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, both), pf, o[d]);
                 }
             }
-
-        if (!TAIL) ME_ATT_WRITE_TILE(buf ^ 1);
-        __syncthreads();
+        }  // active
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the
+                                                             // barrier that lets its slot be restaged
     };
     for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type());
-    tile(nkt - 1, std::true_type());
+    if ((tokens % KT) == 1 && nkt >= 2) {
+        // 577 = 9 x 64 + 1: a whole tile of MFMAs and exponentials for ONE key would be a tenth of the
+        // kernel; that key (row 0 of the tile staged last) is folded in as a rank-one update instead
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (active) {
+            const char* kb = smem + slot * (2 * TILE_BYTES);
+            const char* vb = kb + TILE_BYTES;
+            // s = q . k over this lane's 32 of the 64 dimensions (d = 16 st + 8 h + j), then the other half
+            float dot = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const frag kf = *reinterpret_cast<const frag*>(kb + ((2 * st + h) << 4));  // row 0: no swizzle
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot = __builtin_fmaf((float)kf[j], (float)qf[st][j], dot);
+            }
+            dot += __shfl_xor(dot, 32);
+            const float m_new = fmaxf(m_run, dot);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            const float pv = __builtin_amdgcn_exp2f((dot - m_new) * scale_log2e);
+            m_run = m_new;
+            l_run = l_run * alpha + (h == 0 ? pv : 0.f);  // l is summed over the two lane halves at the end
+            const float p16 = (float)(T)pv;               // P goes through the operand type like every other key's
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    typedef T v4 __attribute__((ext_vector_type(4)));
+                    const v4 vv = *reinterpret_cast<const v4*>(vb + ((4 * d + g4) << 4) + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[d][4 * g4 + e] = __builtin_fmaf(p16, (float)vv[e], o[d][4 * g4 + e] * alpha);
+                }
+        }
+    } else {
+        tile(nkt - 1, std::true_type());
+    }
 
     // ---- normalise and store: lane holds q = q0 + r, d = 32 dblk + 8 (g >> 2) + 4 h + (g & 3)
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -234,8 +308,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
 }
 
-#undef ME_ATT_LOAD_TILE
-#undef ME_ATT_WRITE_TILE
 
 }  // namespace
 
@@ -243,17 +315,19 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
                       int32_t dtype, hipStream_t stream) {
     ME_CHECK(windows > 0 && tokens > 0 && heads > 0, ME_ERR_BAD_SHAPE,
              "attention: windows=%d tokens=%d heads=%d", windows, tokens, heads);
-    ME_CHECK(heads <= 65535 && windows <= 65535, ME_ERR_BAD_SHAPE, "attention: grid too large");
-    const dim3 grid((tokens + 127) / 128, heads, windows);
+    ME_CHECK((int64_t)windows * heads * ((tokens + 127) / 128) < (1ll << 30), ME_ERR_BAD_SHAPE,
+             "attention: grid too large");
+    const int nqb = (tokens + 127) / 128, ngroups = windows * heads;
+    const dim3 grid(8 * nqb * ((ngroups + 7) / 8));
     ProfScope prof(stream, "attention_kernel", 4.0 * windows * heads * (double)tokens * tokens * 64, 0.0);
     // scale = 1/sqrt(64) (vit.rs:47), folded with log2(e) so the softmax runs on exp2
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == ME_DTYPE_F16)
         hipLaunchKernelGGL(attention_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)qkv,
-                           (f16*)out, tokens, heads, scale_log2e);
+                           (f16*)out, tokens, heads, ngroups, scale_log2e);
     else if (dtype == ME_DTYPE_BF16)
         hipLaunchKernelGGL(attention_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)qkv,
-                           (bf16*)out, tokens, heads, scale_log2e);
+                           (bf16*)out, tokens, heads, ngroups, scale_log2e);
     else
         fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
     ME_HIP(hipGetLastError());

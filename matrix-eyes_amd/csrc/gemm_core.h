@@ -44,33 +44,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// The same instruction issued behind the compiler's back (two-group kernel).  The waitcnt pass orders every
-// later LDS access behind a builtin LDS-DMA with vmcnt(0), which would serialise exactly what that kernel
-// overlaps; issued as asm the DMA is invisible to it and the kernel places its own counted waits.  The
-// compiler's own vmcnt waits stay safe: an unknown extra VMEM operation in flight can only make a counted
-// wait longer (returns are in order).  lds_base: wave-uniform LDS byte address; lane l writes base + 16 l.
-// Address = uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no address VALU, half the
-// address registers.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"  // m0 is "reserved": the kernel has no other user of it
-__device__ __forceinline__ void glds16_raw(const void* sbase, unsigned voff, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(lds_base)
-                 : "memory", "m0");
-}
-#pragma clang diagnostic pop
-// a pointer the compiler may hold in VGPRs although every lane has the same value -> SGPR pair
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const uint64_t v = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const char*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-
 // Phi(x) * x with the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121).
 // erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), evaluated on |x| so the negative
 // tail keeps its relative accuracy.
@@ -1092,11 +1065,6 @@ void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     ME_HIP(hipGetLastError());
 }
 
-// s_waitcnt vmcnt(N) with a compile-time N (gfx9 encoding: vmcnt in bits 3:0 and 15:14)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-}
 // vmcnt(rem * P) for a run-time rem in [0, R]
 template <int R, int P>
 struct WaitSlabs {
