@@ -55,10 +55,12 @@ ProfScope::~ProfScope() {
     if (index >= 0) (void)hipEventRecord(profiler().entries[index].e1, stream);
 }
 
-static const char* kCfgNames[] = {"256x256x64/8w", "128x128x64/4w", "64x64x64/4w", "256x128x64/8w",
-                                  "160x128x64/4w", "256x256x64/8w-pp", "64x64x64/4w-ring6"};
-int gemm_num_configs() { return 7; }
-const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < 7 ? kCfgNames[cfg] : "?"; }
+// Tile configurations (the ids are what me_op_* take as tile_cfg)
+static const char* kCfgNames[] = {"256x256x64/8w-pp", "128x128x64/4w", "64x64x64/4w", "160x128x64/4w",
+                                  "64x64x64/4w-ring6"};
+enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_COUNT = 5 };
+int gemm_num_configs() { return CFG_COUNT; }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < CFG_COUNT ? kCfgNames[cfg] : "?"; }
 
 // Tile choice.  The persistent kernels run ceil(tiles / resident workgroups) rounds, so the cost of a
 // configuration is rounds x (tile area) x (workgroups sharing a CU) / (its main-loop efficiency relative
@@ -78,17 +80,17 @@ static int pick_config(int64_t M, int64_t N, int64_t K) {
         // few 64x64 tiles and a long K (the M = 577 fc2: 160 tiles x 64 slabs): the six-slot ring keeps
         // five slabs in flight (33 -> 19 us); with many tiles its 96 KiB of LDS per workgroup costs more
         // in occupancy than the latency it hides
-        return cdiv(M, 64) * cdiv(N, 64) <= 256 && K >= 2048 ? 6 : 2;
+        return cdiv(M, 64) * cdiv(N, 64) <= 256 && K >= 2048 ? CFG_RING64 : CFG_64;
     }
     struct Cand {
         int cfg, bm, bn, per_cu;
         double eff;
     };
-    static const Cand cands[] = {{5, 256, 256, 1, 1.0}, {4, 160, 128, 2, 0.80}, {1, 128, 128, 2, 0.76}};
-    int best = 1;
+    static const Cand cands[] = {{CFG_PP256, 256, 256, 1, 1.0}, {CFG_160, 160, 128, 2, 0.80}, {CFG_128, 128, 128, 2, 0.76}};
+    int best = CFG_128;
     double best_cost = 0.0;
     for (const Cand& c : cands) {
-        if (N < c.bn || (c.cfg == 5 && K < 128)) continue;
+        if (N < c.bn || (c.cfg == CFG_PP256 && K < 128)) continue;
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         // static order: whole rounds; dynamic order: workgroups draw tiles until none are left, so the
         // launch takes the average share plus about half a tile of tail
@@ -161,8 +163,7 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
     int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K);
-    if (cfg == 5 && p.K < 128) cfg = 0;
-    if (cfg == 6 && p.K < 128) cfg = 4;  // the two-group kernel prefetches two slabs ahead
+    if (cfg == CFG_PP256 && p.K < 128) cfg = CFG_128;  // the two-group kernel prefetches two slabs ahead
     static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +

@@ -115,6 +115,45 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
+// Implicit-GEMM addressing shared by the three kernels.  Row m of the A operand is output pixel
+// (b, y, x); its K index is (tap, cin) with a 64-wide slab never straddling a tap (Cin % 64 == 0).
+// conv_pixel: element index / Cin of the tap-(0,0) source pixel of output row gm in the zero-bordered map.
+__device__ __forceinline__ int64_t conv_pixel(const GemmParams& p, int gm) {
+    const int ppi = p.out_H * p.out_W;
+    const int b = gm / ppi;
+    const int rem = gm - b * ppi;
+    const int y = rem / p.out_W;
+    const int x = rem - y * p.out_W;
+    return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
+}
+// Byte offset of K slab kt from a row's tap-(0,0) address.  Slabs are asked for in order (kt = 0 rewinds),
+// so the tap walk is three scalar counters instead of divisions.
+template <int AMODE>
+struct SlabWalk {
+    int cin_steps, pad, kc, ky, kx;
+    __device__ __forceinline__ void init(const GemmParams& p) {
+        cin_steps = AMODE == A_CONV ? p.Cin / 64 : 1;
+        pad = AMODE == A_CONV ? (p.KH - 1) / 2 : 0;
+        kc = ky = kx = 0;
+    }
+    __device__ __forceinline__ int64_t next(const GemmParams& p, int kt) {
+        if constexpr (AMODE == A_PLAIN) {
+            return (int64_t)kt * 128;
+        } else {
+            if (kt == 0) kc = ky = kx = 0;
+            const int64_t off = ((int64_t)(ky + 1 - pad) * p.in_Wp + (kx + 1 - pad)) * p.Cin * 2 + kc * 128;
+            if (++kc == cin_steps) {
+                kc = 0;
+                if (++kx == p.KW) {
+                    kx = 0;
+                    ++ky;
+                }
+            }
+            return off;
+        }
+    }
+};
+
 // block -> tile.  Blocks b and b+8 share an XCD (and its 4 MiB L2), so each XCD gets a contiguous run
 // of the tile order; that order walks "super-rows" of 8 tile rows column by column, so the ~32 tiles
 // an XCD has in flight form an 8 x 4 patch: every A k-slab is shared by 4 of them and every W k-slab
@@ -498,13 +537,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
             if constexpr (AMODE == A_PLAIN) {
                 t.a[i] = (const char*)p.A + ((int64_t)gm * p.lda) * 2 + chunk * 16;
             } else {
-                const int ppi = p.out_H * p.out_W;
-                const int b = gm / ppi;
-                const int rem = gm - b * ppi;
-                const int y = rem / p.out_W;
-                const int x = rem - y * p.out_W;
-                const int64_t pix = ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
-                t.a[i] = (const char*)p.A + pix * p.Cin * 2 + chunk * 16;
+                t.a[i] = (const char*)p.A + conv_pixel(p, gm) * p.Cin * 2 + chunk * 16;
             }
         }
 #pragma unroll
@@ -518,31 +551,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     };
 
     const int nk = p.K / 64;
-    // A_CONV: K index = tap * Cin + cin; a 64-wide slab never straddles a tap (Cin % 64 == 0)
-    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
-    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
-    int tap_kc = 0, tap_ky = 0, tap_kx = 0;  // scalar state of the slab being staged
-
-    // Staging of slab kt of tile t into LDS buffer buf, split so that the caller can place the
-    // A_ITERS + B_ITERS LDS-DMA instructions one by one between MFMA groups (slabs are staged in order:
-    // kt = 0 resets the taps).
-    auto stage_a_offset = [&](int kt) -> int64_t {
-        if constexpr (AMODE == A_PLAIN) {
-            return (int64_t)kt * 128;
-        } else {
-            if (kt == 0) tap_kc = tap_ky = tap_kx = 0;
-            const int64_t off =
-                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
-            if (++tap_kc == cin_steps) {
-                tap_kc = 0;
-                if (++tap_kx == p.KW) {
-                    tap_kx = 0;
-                    ++tap_ky;
-                }
-            }
-            return off;
-        }
-    };
+    // Staging of slab kt of tile t into LDS buffer buf (slabs are staged in order: kt = 0 rewinds the taps)
+    SlabWalk<AMODE> walk;
+    walk.init(p);
+    auto stage_a_offset = [&](int kt) -> int64_t { return walk.next(p, kt); };
     auto stage_piece = [&](const TileSrc& t, int piece, int64_t a_koff, int64_t w_koff, int buf) {
         char* la = smem + buf * STAGE_BYTES;
         if (piece < A_ITERS)
@@ -749,14 +761,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         const char* base;
         unsigned s[IT];
     };
-    auto pixel_of = [&](int gm) -> int64_t {  // A_CONV: first tap-(0,0)-relative element of output row gm
-        const int ppi = p.out_H * p.out_W;
-        const int b = gm / ppi;
-        const int rem = gm - b * ppi;
-        const int y = rem / p.out_W;
-        const int x = rem - y * p.out_W;
-        return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
-    };
+    auto pixel_of = [&](int gm) -> int64_t { return conv_pixel(p, gm); };
     auto setup = [&](Src& t, int vb) {
         tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
         if (group == 0) {
@@ -793,26 +798,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     };
 
     const int nk = p.K / 64;
-    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
-    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
-    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
-    auto stage_a_offset = [&](int kt) -> int64_t {
-        if constexpr (AMODE == A_PLAIN) {
-            return (int64_t)kt * 128;
-        } else {
-            if (kt == 0) tap_kc = tap_ky = tap_kx = 0;
-            const int64_t off =
-                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
-            if (++tap_kc == cin_steps) {
-                tap_kc = 0;
-                if (++tap_kx == p.KW) {
-                    tap_kx = 0;
-                    ++tap_ky;
-                }
-            }
-            return off;
-        }
-    };
+    SlabWalk<AMODE> walk;
+    walk.init(p);
+    auto stage_a_offset = [&](int kt) -> int64_t { return walk.next(p, kt); };
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
     auto stage_T = [&](const Src& t, int kt, int slot) {  // group 0
         const char* base = uniform_ptr(t.base + stage_a_offset(kt));
@@ -1111,14 +1099,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams
 
     // DMA sources: uniform base of the tile's first row + per-lane 32-bit byte offsets
     const int srow = lane >> 3, sslot = lane & 7;
-    auto pixel_of = [&](int gm) -> int64_t {
-        const int ppi = p.out_H * p.out_W;
-        const int b = gm / ppi;
-        const int rem = gm - b * ppi;
-        const int y = rem / p.out_W;
-        const int x = rem - y * p.out_W;
-        return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
-    };
+    auto pixel_of = [&](int gm) -> int64_t { return conv_pixel(p, gm); };
     int64_t a_base_el;
     if constexpr (AMODE == A_PLAIN)
         a_base_el = (int64_t)m0 * p.lda;
@@ -1150,25 +1131,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams
     }
 
     const int nk = p.K / 64;
-    const int cin_steps = (AMODE == A_CONV) ? p.Cin / 64 : 1;
-    const int pad = (AMODE == A_CONV) ? (p.KH - 1) / 2 : 0;
-    int tap_kc = 0, tap_ky = 0, tap_kx = 0;
-    auto stage_a_offset = [&](int kt) -> int64_t {  // slabs are staged in order
-        if constexpr (AMODE == A_PLAIN) {
-            return (int64_t)kt * 128;
-        } else {
-            const int64_t off =
-                ((int64_t)(tap_ky + 1 - pad) * p.in_Wp + (tap_kx + 1 - pad)) * p.Cin * 2 + tap_kc * 128;
-            if (++tap_kc == cin_steps) {
-                tap_kc = 0;
-                if (++tap_kx == p.KW) {
-                    tap_kx = 0;
-                    ++tap_ky;
-                }
-            }
-            return off;
-        }
-    };
+    SlabWalk<AMODE> walk;
+    walk.init(p);
+    auto stage_a_offset = [&](int kt) -> int64_t { return walk.next(p, kt); };
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
     auto stage = [&](int kt, int slot) {
         const char* ab = uniform_ptr(a_base + stage_a_offset(kt));
@@ -1260,13 +1225,11 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
     template <>                                                                           \
     void gemm_dispatch<T, AMODE, EPI>(const GemmParams& p, int cfg, hipStream_t stream) { \
         switch (cfg) {                                                                    \
-            case 0: gemm_launch_cfg<T, 256, 256, 2, 4, AMODE, EPI>(p, stream); break;     \
+            case 0: gemm_launch_pp<T, 256, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
             case 1: gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
-            case 3: gemm_launch_cfg<T, 256, 128, 4, 2, AMODE, EPI>(p, stream); break;     \
-            case 4: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
-            case 5: gemm_launch_pp<T, 256, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
-            case 6: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
+            case 3: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
+            case 4: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

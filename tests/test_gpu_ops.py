@@ -22,7 +22,7 @@ def _check(ctx, rc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, -1])
 @pytest.mark.parametrize("shape", [(577, 256, 128), (1000, 132, 192), (2309, 384, 256), (5000, 512, 64)])
 def test_linear(dtype, cfg, shape):
     M, N, K = shape
@@ -56,7 +56,7 @@ def test_linear_gelu(dtype):
     assert float((out32.double() - ref).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 3])
 @pytest.mark.parametrize("shape", [(20195, 1024, 256), (9000, 2304, 192), (70000, 256, 128)])
 def test_linear_persistent_rounds(cfg, shape):
     """more tiles than resident workgroups: every workgroup walks several tiles, the K stream crosses tile
@@ -91,7 +91,7 @@ def test_dynamic_tile_order_in_a_child_process():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_linear_residual(dtype, cfg):
     M, N, K = 1154, 256, 512
     ctx = ctx_for("tiny", dtype)
@@ -171,7 +171,7 @@ def test_layernorm(dtype, dim):
     dict(B=1, H=12, W=12, Cin=64, Cout=32, k=3, stride=2),
     dict(B=1, H=20, W=20, Cin=128, Cout=64, k=1, stride=1),
 ])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_conv2d(dtype, case, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout, k, s = (case[n] for n in ("B", "H", "W", "Cin", "Cout", "k", "stride"))
@@ -206,7 +206,7 @@ def test_conv2d(dtype, case, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_conv_transpose(dtype, cfg):
     ctx = ctx_for("tiny", dtype)
     B, H, W, Cin, Cout = 2, 18, 18, 128, 64

@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
-DEFAULT = ["qkv:5", "fc1:5", "proj:4", "fc2:4", "conv768:5", "attn:0"]
+DEFAULT = ["qkv:0", "fc1:0", "proj:3", "fc2:3", "conv768:0", "attn:0"]
 KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_ring_kernel", "attention_kernel")
 
 
