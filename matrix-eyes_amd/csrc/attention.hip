@@ -4,9 +4,11 @@
 // SURVEY §3.2) never leaves registers.
 //
 // One workgroup = 4 waves = 128 query rows of one (window, head); each wave owns 32 queries.
-// K/V tiles of 64 keys go global -> LDS by LDS-DMA into a three-slot ring, two tiles ahead of the
-// one being consumed: with one tile of distance (registers, double buffered) every tile waited out a
-// global-load latency -- 1.6 us per tile for a lone workgroup, whatever it computed.  Per tile and wave:
+// K/V tiles of 64 keys go global -> LDS by LDS-DMA into a ring of NSLOT slots (no staging registers, no
+// per-tile address arithmetic).  Measured on one box: two slots with the registers capped for 4 waves per
+// SIMD 0.0783 ms at 35 windows, two or three slots at 3 waves per SIMD 0.082 -- the kernel does not wait
+// for K/V (a second tile of prefetch distance buys nothing), it is bound by each wave's dependent
+// MFMA -> softmax -> MFMA chain, and a fourth wave per SIMD covers more of it.  Per tile and wave:
 //   S^T[key][q] = K[key][:] . Q[q][:]          8 x v_mfma_f32_32x32x16 (K tile = A operand)
 //   online softmax with the key index in registers and the query on the lane, so row max/sum
 //   are in-lane plus one cross-half exchange
@@ -46,10 +48,11 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
 
 constexpr int KT = 64;            // keys per LDS tile
 constexpr int TILE_BYTES = KT * 128;
-constexpr int NSLOT = 3;           // LDS ring slots (K + V tile each)
 
-template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
+// NSLOT: LDS ring slots (a K and a V tile each; 2 or 3); MINW: waves per SIMD the register allocation
+// must allow (launched as <2, 4>: 32 KiB of LDS and 128 VGPRs, three of them spilled)
+template <typename T, int NSLOT, int MINW>
+__global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int tokens, int heads,
                                                         int ngroups, float scale_log2e) {
     typedef typename Mfma32<T>::frag frag;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const int nkt = (tokens + KT - 1) / KT;
     stage_offsets(0);
     stage(0);
-    if (nkt > 1) {
+    if (NSLOT == 3 && nkt > 1) {
         stage_offsets(1);
         stage(1);
     }
@@ -152,17 +155,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     // flight), barrier (everybody's pieces have landed; everybody is done with tile kt-1), restage the slot
     // of tile kt-1 with tile kt+2, compute.
     const bool active = q0 < tokens;
-    int slot = 0, fill = 2;
+    int slot = 0, fill = NSLOT - 1;
     auto tile = [&](int kt, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        if (kt + 1 < nkt)
-            wait_vmcnt<4>();
+        if (NSLOT == 3 && kt + 1 < nkt)
+            wait_vmcnt<4>();  // the next tile's pieces may stay in flight
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < nkt) {
-            stage_offsets(kt + 2);
+        if (kt + NSLOT - 1 < nkt) {
+            stage_offsets(kt + NSLOT - 1);
             stage(fill);
         }
         const char* kb = smem + slot * (2 * TILE_BYTES);
@@ -323,10 +326,10 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
     // scale = 1/sqrt(64) (vit.rs:47), folded with log2(e) so the softmax runs on exp2
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == ME_DTYPE_F16)
-        hipLaunchKernelGGL(attention_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)qkv,
+        hipLaunchKernelGGL((attention_kernel<f16, 2, 4>), grid, dim3(256), 0, stream, (const f16*)qkv,
                            (f16*)out, tokens, heads, ngroups, scale_log2e);
     else if (dtype == ME_DTYPE_BF16)
-        hipLaunchKernelGGL(attention_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)qkv,
+        hipLaunchKernelGGL((attention_kernel<bf16, 2, 4>), grid, dim3(256), 0, stream, (const bf16*)qkv,
                            (bf16*)out, tokens, heads, ngroups, scale_log2e);
     else
         fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
