@@ -1,0 +1,148 @@
+"""The C++ host layer (matrix-eyes_amd/host/): the compiled twin of the reference's main.rs /
+reconstruction.rs / DepthProModelLoader above the C ABI.  CPU part: checkpoint reader against torch, PNG
+codec and Lanczos3 against Pillow, CLI usage and exit codes.  GPU part (-m gpu): the CLI end to end on the
+test geometry, against the Python mirror driving the same library."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "matrix-eyes_amd")
+SELFTEST = os.path.join(PKG, "host_selftest")
+CLI = os.path.join(PKG, "matrix-eyes-hip")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
+    assert os.path.exists(SELFTEST) and os.path.exists(CLI)
+
+
+def _fnv1a64(b: bytes) -> int:
+    h = 1469598103934665603
+    for x in np.frombuffer(b, np.uint8).tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _tiny_checkpoint(path):
+    import matrix_eyes_amd as m
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint
+    ck = {k: torch.as_tensor(v) for k, v in synthetic_checkpoint(m.ModelConfig.tiny()).items()}
+    torch.save(ck, path)
+    return ck
+
+
+def test_checkpoint_reader_matches_torch(tmp_path):
+    ck = _tiny_checkpoint(str(tmp_path / "tiny.pt"))
+    r = subprocess.run([SELFTEST, "pt", str(tmp_path / "tiny.pt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert [l[0] for l in lines] == list(ck.keys())            # state_dict order is kept
+    names = {torch.float16: "f16", torch.float32: "f32"}
+    for l in lines[:: max(1, len(lines) // 40)]:               # every ~7th tensor: shape, dtype, bytes
+        t = ck[l[0]].contiguous()
+        assert l[1] == names[t.dtype] and [int(x) for x in l[2:-1]] == list(t.shape)
+        assert int(l[-1], 16) == _fnv1a64(t.numpy().tobytes())
+
+
+def test_checkpoint_reader_errors(tmp_path):
+    bad = tmp_path / "bad.pt"
+    bad.write_bytes(b"not a zip archive at all, just some bytes" * 3)
+    r = subprocess.run([SELFTEST, "pt", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "zip" in r.stderr
+    r = subprocess.run([SELFTEST, "pt", str(tmp_path / "missing.pt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P"])
+def test_png_codec_against_pillow(tmp_path, mode):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = Image.fromarray(rng.integers(0, 256, (41, 67, 3), dtype=np.uint8)).convert(mode)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    img.save(src)
+    r = subprocess.run([SELFTEST, "png", src, dst], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.asarray(Image.open(dst)), np.asarray(img.convert("RGB")))
+
+
+@pytest.mark.parametrize("size", [(150, 100), (512, 384), (300, 200)])
+def test_lanczos3_against_pillow(tmp_path, size):
+    from PIL import Image
+    rng = np.random.default_rng(6)
+    big = Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).resize((300, 200), Image.BICUBIC)
+    src, dst = str(tmp_path / "big.png"), str(tmp_path / "rs.png")
+    big.save(src)
+    r = subprocess.run([SELFTEST, "resize", src, str(size[0]), str(size[1]), dst], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.asarray(Image.open(dst)).astype(int)
+    want = np.asarray(big.resize(size, Image.LANCZOS)).astype(int)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1     # one code of rounding at most
+
+
+def test_cli_usage_and_exit_codes(tmp_path):
+    r = subprocess.run([CLI, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage: matrix-eyes [OPTIONS] <IMG_SRC>... <IMG_OUT>" in r.stdout
+    from matrix_eyes_amd.cli import USAGE_INSTRUCTIONS
+    assert USAGE_INSTRUCTIONS in r.stdout                       # the same text as the Python twin
+    for argv, msg in [([], "No source image provided"), (["a.png"], "No output image provided"),
+                      (["--mesh=cubes", "a.png", "b.obj"], "Unsupported mesh vertex output mode cubes"),
+                      (["--focal-length", "a.png", "b.png"], "Option flag --focal-length has no value"),
+                      (["--resize-scale=big", "a.png", "b.png"], "Argument --resize-scale has an unsupported value big"),
+                      (["a.png", "b.png", "c.png"], "Unexpected argument c.png")]:
+        r = subprocess.run([CLI] + argv, capture_output=True, text=True)
+        assert r.returncode == 2 and msg in r.stderr, (argv, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_against_the_python_mirror(tmp_path):
+    """depth map PNG, stereogram PNG and OBJ from the compiled CLI == the Python mirror on the same inputs"""
+    from PIL import Image
+    import matrix_eyes_amd as m
+    from matrix_eyes_amd.synthetic import synthetic_images
+    cfg = m.ModelConfig.tiny()
+    ckpt = str(tmp_path / "tiny.pt")
+    _tiny_checkpoint(ckpt)
+    S = cfg.img_size
+    src = str(tmp_path / "photo.png")
+    Image.fromarray(synthetic_images(1, S, "structured", seed=11)[0]).save(src)
+    env = dict(os.environ, MATRIX_EYES_MODEL="tiny", MATRIX_EYES_SEED="7")
+
+    def cli(*args):
+        r = subprocess.run([CLI, f"--checkpoint-path={ckpt}", "--focal-length=35", *args], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.startswith("Matrix Eyes version")
+
+    loader = m.DepthProModelLoader(ckpt, False, cfg)
+    from matrix_eyes_amd import reconstruction as R
+
+    cli(src, str(tmp_path / "depth_cpp.png"))
+    R.extract_depth(0, loader, src, str(tmp_path / "depth_py.png"), 35.0, m.ImageOutputFormat.DepthMap(),
+                    m.VertexMode.Color)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "depth_cpp.png")),
+                          np.asarray(Image.open(tmp_path / "depth_py.png")))
+
+    cli("--mesh=texture-coordinates", src, str(tmp_path / "mesh_cpp.obj"))
+    R.extract_depth(0, loader, src, str(tmp_path / "mesh_py.obj"), 35.0, m.ImageOutputFormat.DepthMap(),
+                    m.VertexMode.Texture)
+    cpp, py = (tmp_path / "mesh_cpp.obj").read_text(), (tmp_path / "mesh_py.obj").read_text()
+    assert cpp.replace("mesh_cpp", "mesh") == py.replace("mesh_py", "mesh") and len(cpp) > 1000
+
+    cli("--image-output-format=stereogram", "--resize-scale=0.5", src, str(tmp_path / "stereo_cpp.png"))
+    st = np.asarray(Image.open(tmp_path / "stereo_cpp.png"))
+    assert st.shape == (S // 2, S // 2, 3)
+    # same seed, same picture; the autostereogram property: rows repeat with the pattern period where flat
+    cli("--image-output-format=stereogram", "--resize-scale=0.5", src, str(tmp_path / "stereo_cpp2.png"))
+    assert np.array_equal(st, np.asarray(Image.open(tmp_path / "stereo_cpp2.png")))
+
+    r = subprocess.run([CLI, f"--checkpoint-path={tmp_path / 'none.pt'}", src, str(tmp_path / "x.png")], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Reconstruction failed" in r.stdout
