@@ -5,6 +5,8 @@
 //   - conv stages: NHWC; 16-bit operands of 3x3 convs carry a 1-pixel zero border
 //     ([B][H+2][W+2][C]) so the implicit-GEMM loader needs no bounds checks, residual paths
 //     stay f32 ([B*H*W][C]).
+#include <memory>
+
 #include "model.h"
 
 namespace me {
@@ -158,29 +160,41 @@ void tap_fn(void* user, int index, const float* tokens) {
 
 }  // namespace
 
-// vit.rs:287-346: prepare_tokens_with_mask, 24 x Block::forward, final LayerNorm
-void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
-                 void* final16, float* final32, const std::string& tag, hipStream_t s) {
-    const VitW& v = ctx->w.vit[which];
-    const int C = ctx->C(), T = ctx->T(), P = ctx->P(), heads = ctx->cfg.num_heads;
-    const int64_t rows = (int64_t)W * T;
-    float* tok = (float*)site_buf(ctx, tag + ".tokens", (size_t)rows * C * 4);
-    void* xn = site_buf(ctx, tag + ".xn", (size_t)rows * C * 2);
-    void* qkv = site_buf(ctx, tag + ".qkv", (size_t)rows * 3 * C * 2);
-    void* att = site_buf(ctx, tag + ".att", (size_t)rows * C * 2);
-    void* hid = site_buf(ctx, tag + ".hid", (size_t)rows * 4 * C * 2);
+// vit.rs:287-346: prepare_tokens_with_mask, 24 x Block::forward, final LayerNorm -- as an object, so
+// that the encoder can issue the three ViTs block by block in turn (see stage_encoder).
+namespace {
+struct VitRun {
+    me_ctx* ctx;
+    const VitW& v;
+    int W;
+    VitTaps taps;
+    hipStream_t s;
+    int64_t rows;
+    float* tok;
+    void *xn, *qkv, *att, *hid;
 
     // vit.rs:287-295: patch embed + cls + pos
-    cls_rows_launch(tok, v.cls, v.pos, W, T, C, s);
-    {
+    VitRun(me_ctx* ctx_, int which, const void* patches16, int W_, const VitTaps& taps_, const std::string& tag,
+           hipStream_t s_)
+        : ctx(ctx_), v(ctx_->w.vit[which]), W(W_), taps(taps_), s(s_) {
+        const int C = ctx->C(), T = ctx->T(), P = ctx->P();
+        rows = (int64_t)W * T;
+        tok = (float*)site_buf(ctx, tag + ".tokens", (size_t)rows * C * 4);
+        xn = site_buf(ctx, tag + ".xn", (size_t)rows * C * 2);
+        qkv = site_buf(ctx, tag + ".qkv", (size_t)rows * 3 * C * 2);
+        att = site_buf(ctx, tag + ".att", (size_t)rows * C * 2);
+        hid = site_buf(ctx, tag + ".hid", (size_t)rows * 4 * C * 2);
+        cls_rows_launch(tok, v.cls, v.pos, W, T, C, s);
         GemmParams p = base_params();
         p.M = W * P, p.N = C, p.K = 768, p.A = patches16, p.lda = 768, p.W = v.patch_w;
         p.bias = v.patch_b, p.pos = v.pos, p.out32 = tok, p.ldc = C, p.tokens_per_window = P;
         gemm_launch(p, A_PLAIN, EPI_PATCH_EMBED, ctx->dtype, s);
     }
-    for (int i = 0; i < ctx->cfg.depth; ++i) {
+
+    // vit.rs:163-170 Block::forward
+    void block(int i) {
         const VitBlockW& b = v.blocks[i];
-        // vit.rs:163-170 Block::forward
+        const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
         layernorm_launch(tok, b.ln1_w, b.ln1_b, xn, nullptr, rows, C, ctx->cfg.ln_eps, ctx->dtype, s);
         linear(ctx, xn, rows, C, b.qkv_w, 3 * C, b.qkv_b, qkv, nullptr, 3 * C, ACT_NONE, s);
         attention_launch(qkv, att, W, T, heads, ctx->dtype, s);
@@ -200,9 +214,19 @@ void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const Vit
         }
         if (taps.fn) taps.fn(taps.user, i, tok);
     }
+
     // vit.rs:343 final norm
-    layernorm_launch(tok, v.norm_w, v.norm_b, final16, final32, rows, C, ctx->cfg.ln_eps, ctx->dtype,
-                     s);
+    void finish(void* final16, float* final32) {
+        layernorm_launch(tok, v.norm_w, v.norm_b, final16, final32, rows, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s);
+    }
+};
+}  // namespace
+
+void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
+                 void* final16, float* final32, const std::string& tag, hipStream_t s) {
+    VitRun run(ctx, which, patches16, W, taps, tag, s);
+    for (int i = 0; i < ctx->cfg.depth; ++i) run.block(i);
+    run.finish(final16, final32);
 }
 
 // encoder.rs:218-335 DepthProEncoder::forward_encodings
@@ -235,31 +259,47 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     TapCtx tc{ctx, B, lat0, lat1, s};
     VitTaps taps;
     taps.fn = tap_fn, taps.user = &tc;
-    vit_forward(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, tok16, nullptr, "vit.patch", s);
     // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend
-    // only on x2, so they run on the side streams beside the patch encoder.  They are ENQUEUED after it:
-    // the host needs ~3 ms to issue their ~400 small launches, and the main stream must not sit empty
-    // meanwhile (it did: 3.8 ms of the step, rocprofv3 trace); they still finish long before the joins.
-    {
-        hipStream_t s1 = ctx->side[0];
-        ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
-        void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
-        patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
-        void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
-#ifdef ME_DEBUG_HOOKS  // timing experiment only (results are garbage): the step without the side ViTs
-        if (!getenv("ME_DEBUG_SKIP_SIDE"))
-#endif
-            vit_forward(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), tokg16, nullptr, "vit.image", s1);
-        merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s1);
-        ME_HIP(hipEventRecord(ctx->ev_img, s1));
-    }
-    if (fov_async) {
-        hipStream_t s2 = ctx->side[1];
+    // only on x2, so they run on the side streams beside the patch encoder.  The three ViTs are ISSUED
+    // block by block in turn: the side chains are the last thing the decoder waits for, so they must not
+    // start a whole patch-encoder's worth of host launches late, and the launch stream must not sit empty
+    // while ~350 small side launches are issued either (it did: 3.8 ms of the step in a rocprofv3 trace).
+    hipStream_t s1 = ctx->side[0], s2 = ctx->side[1];
+    ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
+    void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
+    patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
+    void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
+    void* fov_tok16 = nullptr;
+    if (fov_async) {  // stage_fov_vit, issued in step with the others
         ME_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        stage_fov_vit(ctx, B, s2);
+        report(ctx, 0.0f, "encoding fov");
+        void* fpatches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
+        patchify_windows_launch(x2, fpatches, B, g, ctx->dtype, s2);
+        fov_tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
+    }
+    {
+        VitRun main_run(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, "vit.patch", s);
+        VitRun img_run(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), "vit.image", s1);
+        std::unique_ptr<VitRun> fov_run;
+        if (fov_async)
+            fov_run.reset(new VitRun(ctx, ME_VIT_FOV_ENCODER, ctx->bufs.at("fov.patches").p, B, VitTaps(), "vit.fov", s2));
+        for (int i = 0; i < c.depth; ++i) {
+            main_run.block(i);
+            img_run.block(i);
+            if (fov_run) fov_run->block(i);
+        }
+        main_run.finish(tok16, nullptr);
+        img_run.finish(tokg16, nullptr);
+        if (fov_run) fov_run->finish(fov_tok16, nullptr);
+    }
+    merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s1);
+    ME_HIP(hipEventRecord(ctx->ev_img, s1));
+    if (fov_async) {
+        float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
+        linear(ctx, fov_tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
+               dec / 2, ACT_NONE, s2);
         ME_HIP(hipEventRecord(ctx->ev_fov, s2));
     }
-
     report(ctx, 0.55f, "reshaping patch encodings");
     // encoder.rs:263,285-294: split_with_sizes + merge
     void* x0f = site_buf(ctx, "enc.x0f", (size_t)B * side0 * side0 * C * 2);
