@@ -406,11 +406,32 @@ int32_t me_fov_forward(me_ctx* ctx, const float* x, const float* lowres_feature,
 }
 
 namespace {
+// the range a stage reports into, restored on scope exit (also when a stage throws)
+struct ProgressRange {
+    me_ctx* ctx;
+    ProgressRange(me_ctx* c, float lo, float hi) : ctx(c) { ctx->prog_lo = lo, ctx->prog_hi = hi; }
+    ~ProgressRange() { ctx->prog_lo = 0.0f, ctx->prog_hi = 1.0f; }
+};
+
 void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const float* f_norm,
                         float* inverse_depth, float* fov_deg_out) {
     const int S = ctx->S();
-    stage_encoder(ctx, img_dev, batch, f_norm == nullptr);
-    stage_decoder(ctx, batch, false);
+    // mod.rs:265-293,345: the reference splits its progress bar 80 / 20 between depth and FOV when the FOV
+    // head runs, the depth part 80 / 20 between encoder and the rest, that 98 / 2 between decoder and head,
+    // and gives the first 5 % of each part to loading its weights (resident here).  The FOV tail runs
+    // before the head in this pipeline (f_norm is divided out inside the head's last kernel), so it takes
+    // the range between decoder and head.
+    const float depth_end = f_norm ? 1.0f : 0.8f;
+    const float enc_end = 0.8f * depth_end, dec_end = enc_end + 0.98f * (depth_end - enc_end);
+    {
+        ProgressRange r(ctx, 0.05f * enc_end, enc_end);
+        stage_encoder(ctx, img_dev, batch, f_norm == nullptr);
+    }
+    {
+        ProgressRange r(ctx, enc_end + 0.05f * (dec_end - enc_end), dec_end);
+        stage_decoder(ctx, batch, false);
+    }
+    const float head_lo = f_norm ? dec_end : 0.99f;
     float* fnorm_dev = (float*)site_buf(ctx, "f_norm", (size_t)batch * 4);
     OutBuf ofov;
     if (f_norm) {
@@ -423,10 +444,14 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     } else {
         // mod.rs:343-358
         ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
+        ProgressRange r(ctx, dec_end, head_lo);
         stage_fov_tail(ctx, batch, (float*)ofov.dev, true);
     }
     OutBuf o = out_buf(ctx, inverse_depth, (size_t)batch * S * S * 4, "io.depth");
-    stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev);
+    {
+        ProgressRange r(ctx, head_lo, 1.0f);
+        stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev);
+    }
     finish(ctx, o);
     if (!f_norm && fov_deg_out) finish(ctx, ofov);
     report(ctx, 1.0f, nullptr);

@@ -90,6 +90,8 @@ struct me_ctx {
     std::string last_error;
     me_progress_fn progress = nullptr;
     void* progress_user = nullptr;
+    // SplitProgressListener (mod.rs:374-414): a stage's positions in [0,1] are mapped into this range
+    float prog_lo = 0.0f, prog_hi = 1.0f;
 
     // weights
     std::vector<me::WeightSlot> slots;

@@ -12,7 +12,8 @@
 namespace me {
 
 void report(me_ctx* ctx, float pos, const char* msg) {
-    if (ctx->progress) ctx->progress(ctx->progress_user, pos, msg);
+    if (ctx->progress)
+        ctx->progress(ctx->progress_user, ctx->prog_lo + pos * (ctx->prog_hi - ctx->prog_lo), msg);
 }
 
 bool is_device_ptr(const void* p) {
@@ -272,7 +273,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     void* fov_tok16 = nullptr;
     if (fov_async) {  // stage_fov_vit, issued in step with the others
         ME_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        report(ctx, 0.0f, "encoding fov");
+        report(ctx, 0.03f, "encoding fov");
         void* fpatches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
         patchify_windows_launch(x2, fpatches, B, g, ctx->dtype, s2);
         fov_tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);

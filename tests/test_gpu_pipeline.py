@@ -169,6 +169,13 @@ def test_progress_callback():
     ctx.extract_depth(synthetic_images(1, ctx.cfg.img_size), None)
     ctx.set_progress(None)
     assert seen and seen[-1][0] == 1.0 and any(msg == "encoding patches" for _, msg in seen)
+    # mod.rs:265-293: one bar for the whole call -- the encoder ends at 64 %, the decoder at 79.68 % when
+    # the FOV head runs; the positions only move forward
+    pos = [p for p, msg in seen]
+    assert all(b >= a - 1e-6 for a, b in zip(pos, pos[1:])) and 0.0 <= min(pos) and max(pos) == 1.0
+    by_msg = {msg: p for p, msg in seen}
+    assert abs(by_msg["fusing lowres"] - (0.032 + 0.95 * (0.64 - 0.032))) < 1e-5
+    assert abs(by_msg["forwarding head"] - 0.99) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", ["f16"])
