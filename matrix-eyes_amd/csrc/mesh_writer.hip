@@ -1,11 +1,14 @@
 // output.rs:195-261 output_mesh and its two writers (ObjWriter :484-630, PlyWriter :385-482).
 // Vertex ids, faces and coordinates come from the GPU kernels in output.hip; this file is the
 // host-side serialisation, byte-for-byte the reference's text/binary layout.
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "model.h"
@@ -64,6 +67,70 @@ struct FileSink {
         ME_CHECK(r == 0, ME_ERR_IO, "close failed: %s", strerror(errno));
     }
 };
+
+// One section of the file (all "vt" lines, all "v" lines, all faces ...): `item(i, out)` appends item i.
+// A 1536^2 textured OBJ is 450 MB of shortest-round-trip decimals, 0.59 s single-threaded beside a 26 ms
+// forward pass; the items are independent, so chunks of 32 Ki items are formatted by up to 12 host threads
+// into their own strings and copied into the file with pwrite at the offsets the sizes give (0.23 s): the
+// bytes are those of the sequential loop.
+template <typename Item>
+void write_section(FileSink& w, int64_t count, Item item, bool threads = true) {
+    constexpr int64_t kChunk = 32768;
+    const int64_t nchunks = (count + kChunk - 1) / kChunk;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = threads ? (int)std::min<int64_t>(nchunks, hw ? (hw > 12 ? 12 : hw) : 4) : 1;
+    if (nthreads <= 1) {
+        for (int64_t i = 0; i < count; ++i) {
+            w.flush_if_full();
+            item(i, w.buf);
+        }
+        return;
+    }
+    w.flush();
+    std::vector<std::string> chunks((size_t)nchunks);
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (int64_t c; (c = next.fetch_add(1)) < nchunks;) {
+            std::string& out = chunks[(size_t)c];
+            out.reserve(1 << 20);
+            const int64_t end = std::min(count, (c + 1) * kChunk);
+            for (int64_t i = c * kChunk; i < end; ++i) item(i, out);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+    // the same threads then copy their chunks into the file at the offsets the sizes give
+    ME_CHECK(fflush(w.f) == 0, ME_ERR_IO, "write failed: %s", strerror(errno));
+    const off_t base = ftello(w.f);
+    std::vector<off_t> offset((size_t)nchunks + 1, base);
+    for (int64_t c = 0; c < nchunks; ++c) offset[(size_t)c + 1] = offset[(size_t)c] + (off_t)chunks[(size_t)c].size();
+    const int fd = fileno(w.f);
+    std::atomic<int64_t> next_w{0};
+    std::atomic<int> failed{0};
+    auto put = [&]() {
+        for (int64_t c; (c = next_w.fetch_add(1)) < nchunks;) {
+            const std::string& out = chunks[(size_t)c];
+            size_t done = 0;
+            while (done < out.size()) {
+                const ssize_t r = pwrite(fd, out.data() + done, out.size() - done, offset[(size_t)c] + (off_t)done);
+                if (r <= 0) {
+                    failed = errno ? errno : EIO;
+                    return;
+                }
+                done += (size_t)r;
+            }
+            std::string().swap(chunks[(size_t)c]);
+        }
+    };
+    pool.clear();
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(put);
+    put();
+    for (std::thread& t : pool) t.join();
+    ME_CHECK(failed == 0, ME_ERR_IO, "write failed: %s", strerror(failed));
+    ME_CHECK(fseeko(w.f, offset[(size_t)nchunks], SEEK_SET) == 0, ME_ERR_IO, "seek failed: %s", strerror(errno));
+}
 
 bool ends_with_ci(const std::string& s, const char* suffix) {
     const size_t n = strlen(suffix);
@@ -169,16 +236,14 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                 b += "usemtl Textured\n";
             }
             if (tex)  // output.rs:592-602
-                for (int64_t i = 0; i < nverts; ++i) {
-                    w.flush_if_full();
+                write_section(w, nverts, [&](int64_t i, std::string& b) {
                     b += "vt ";
                     put_f64(b, (double)uv[2 * i]);
                     b += ' ';
                     put_f64(b, 1.0 - (double)uv[2 * i + 1]);
                     b += '\n';
-                }
-            for (int64_t i = 0; i < nverts; ++i) {  // output.rs:566-590
-                w.flush_if_full();
+                });
+            write_section(w, nverts, [&](int64_t i, std::string& b) {  // output.rs:566-590
                 b += "v ";
                 put_f64(b, (double)xyz[3 * i]);
                 b += ' ';
@@ -191,9 +256,8 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                         put_f64(b, (double)colors[3 * i + c] / 255.0);
                     }
                 b += '\n';
-            }
-            for (int64_t f = 0; f < nfaces; ++f) {  // output.rs:604-620
-                w.flush_if_full();
+            });
+            write_section(w, nfaces, [&](int64_t f, std::string& b) {  // output.rs:604-620
                 b += 'f';
                 for (int k = 0; k < 3; ++k) {
                     const unsigned long long idx = (unsigned long long)faces[3 * f + k] + 1;
@@ -205,7 +269,7 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                     }
                 }
                 b += '\n';
-            }
+            });
             w.close();
             if (tex) {  // output.rs:525-547 write_materials
                 const std::string dir = parent_dir(dest);
@@ -225,18 +289,16 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                 b += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
             b += "element face " + std::to_string(nfaces) + "\n";
             b += "property list uchar int vertex_indices\nend_header\n";
-            for (int64_t i = 0; i < nverts; ++i) {  // output.rs:440-458
-                w.flush_if_full();
+            write_section(w, nverts, [&](int64_t i, std::string& b) {  // output.rs:440-458
                 put_be64(b, (double)xyz[3 * i]);
                 put_be64(b, (double)(-xyz[3 * i + 1]));
                 put_be64(b, (double)(-xyz[3 * i + 2]));
                 if (with_color) b.append((const char*)&colors[3 * i], 3);
-            }
-            for (int64_t f = 0; f < nfaces; ++f) {  // output.rs:464-473
-                w.flush_if_full();
+            }, false);  // binary: a byte shuffle per item, not worth the second copy
+            write_section(w, nfaces, [&](int64_t f, std::string& b) {  // output.rs:464-473
                 b.push_back((char)3);
                 for (int k = 0; k < 3; ++k) put_be32(b, (uint32_t)faces[3 * f + k]);
-            }
+            }, false);
             w.close();
         }
     } catch (const me::Error& e) {
