@@ -54,7 +54,7 @@ constexpr int TILE_BYTES = KT * 128;
 template <typename T, int NSLOT, int MINW>
 __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int tokens, int heads,
-                                                        int ngroups, float scale_log2e) {
+                                                        int ngroups, float scale_log2e, RowSegs segs) {
     typedef typename Mfma32<T>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
     if (group >= ngroups) return;               // uniform: the whole workgroup leaves before any barrier
     const int win = group / heads, head = group - win * heads;
     const int q0 = qblk * 128 + wave * 32;
-    const int64_t row0 = (int64_t)win * tokens;
+    // first row of the window: windows are `tokens` rows apart inside a row segment (RowSegs)
+    int64_t row0 = (int64_t)win * tokens;
+    if (segs.seg1 && win >= segs.win0)
+        row0 = win < segs.win0 + segs.win1 ? segs.seg1 + (int64_t)(win - segs.win0) * tokens
+                                           : segs.seg2 + (int64_t)(win - segs.win0 - segs.win1) * tokens;
     const T* qbase = qkv + head * 64;
     const T* kbase = qkv + C + head * 64;
     const T* vbase = qkv + 2 * C + head * 64;
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
 }  // namespace
 
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
-                      int32_t dtype, hipStream_t stream) {
+                      int32_t dtype, hipStream_t stream, const RowSegs* segs_opt) {
+    const RowSegs segs = segs_opt ? *segs_opt : RowSegs();
     ME_CHECK(windows > 0 && tokens > 0 && heads > 0, ME_ERR_BAD_SHAPE,
              "attention: windows=%d tokens=%d heads=%d", windows, tokens, heads);
     ME_CHECK((int64_t)windows * heads * ((tokens + 127) / 128) < (1ll << 30), ME_ERR_BAD_SHAPE,
@@ -327,10 +332,10 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == ME_DTYPE_F16)
         hipLaunchKernelGGL((attention_kernel<f16, 2, 4>), grid, dim3(256), 0, stream, (const f16*)qkv,
-                           (f16*)out, tokens, heads, ngroups, scale_log2e);
+                           (f16*)out, tokens, heads, ngroups, scale_log2e, segs);
     else if (dtype == ME_DTYPE_BF16)
         hipLaunchKernelGGL((attention_kernel<bf16, 2, 4>), grid, dim3(256), 0, stream, (const bf16*)qkv,
-                           (bf16*)out, tokens, heads, ngroups, scale_log2e);
+                           (bf16*)out, tokens, heads, ngroups, scale_log2e, segs);
     else
         fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
     ME_HIP(hipGetLastError());

@@ -162,6 +162,12 @@ struct GemmParams {
     int32_t pixels_per_image;
     // diagnostic builds only (tools/gemm_stamps.py): per-workgroup s_memrealtime stamps, or null
     unsigned long long* stamps;
+    // Row segments with their own weights (the three ViTs of the encoder in one launch, pipeline.hip):
+    // rows [0, seg1) use W / bias / gamma, [seg1, seg2) the *_s1 set, [seg2, M) the *_s2 set.  seg1 == 0:
+    // one segment.  seg2 == 0: two.  Both must be multiples of the tile height (checked at launch).
+    int32_t seg1, seg2;
+    const void *W_s1, *W_s2;
+    const float *bias_s1, *bias_s2, *gamma_s1, *gamma_s2;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).
@@ -179,15 +185,23 @@ const char* gemm_config_name(int cfg);
 // Attention: qkv [rows][3*C] (q | k | v, each [heads][64]), rows = windows * tokens;
 // out [rows][C].  softmax(q*scale . k^T) v per (window, head); head_dim is 64.
 // ---------------------------------------------------------------------------------------
+// Row segments of the encoder's merged ViT launches (pipeline.hip): segment 0 = rows [0, seg1), 1 =
+// [seg1, seg2), 2 = [seg2, ...).  Windows are contiguous (stride `tokens` rows) inside a segment; win0 /
+// win1 are the numbers of windows of segments 0 and 1.  seg1 == 0: no segmentation.
+struct RowSegs {
+    int64_t seg1 = 0, seg2 = 0;
+    int32_t win0 = 0, win1 = 0;
+    const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;  // LayerNorm weights of 1 and 2
+};
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
-                      int32_t dtype, hipStream_t stream);
+                      int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr);
 
 // ---------------------------------------------------------------------------------------
 // Row-wise and layout kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------
 // y16[r][:] = (x[r][:] - mean) / sqrt(var + eps) * w + b ; optional f32 copy y32.
 void layernorm_launch(const float* x, const float* w, const float* b, void* y16, float* y32,
-                      int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream);
+                      int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr);
 // u8 HWC -> f32 NCHW, reconstruction.rs:114-124
 void preprocess_u8_launch(const uint8_t* rgb, float* img, int32_t batch, int32_t size,
                           hipStream_t stream);

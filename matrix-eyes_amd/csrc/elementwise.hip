@@ -27,13 +27,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         T* __restrict__ y16, float* __restrict__ y32,
-                                                        int64_t rows, float eps) {
+                                                        int64_t rows, float eps, RowSegs segs) {
     constexpr int DIM = NPL * 64;
     constexpr int V = (NPL % 4 == 0) ? 4 : 1;  // elements per access
     constexpr int NA = NPL / V;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (segs.seg1 && row >= segs.seg1) {  // wave-uniform: a wave owns one row
+        const bool third = segs.seg2 && row >= segs.seg2;
+        w = third ? segs.w2 : segs.w1;
+        b = third ? segs.b2 : segs.b1;
+    }
     const float* xr = x + row * DIM;
     float v[NPL];
 #pragma unroll
@@ -84,11 +89,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 template <typename T>
 void layernorm_typed(const float* x, const float* w, const float* b, void* y16, float* y32,
-                     int64_t rows, int32_t dim, float eps, hipStream_t stream) {
+                     int64_t rows, int32_t dim, float eps, hipStream_t stream, const RowSegs& segs) {
     const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
 #define ME_LN(NPL)                                                                          \
     hipLaunchKernelGGL((layernorm_kernel<T, NPL>), grid, block, 0, stream, x, w, b, (T*)y16, y32, \
-                       rows, eps)
+                       rows, eps, segs)
     switch (dim / 64) {
         case 1: ME_LN(1); break;
         case 2: ME_LN(2); break;
@@ -462,12 +467,14 @@ inline unsigned grid_for(int64_t total, int block = 256) {
     } while (0)
 
 void layernorm_launch(const float* x, const float* w, const float* b, void* y16, float* y32,
-                      int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream) {
+                      int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream,
+                      const RowSegs* segs_opt) {
+    const RowSegs segs = segs_opt ? *segs_opt : RowSegs();
     ME_CHECK(dim % 64 == 0 && rows > 0, ME_ERR_BAD_SHAPE, "layernorm: rows=%lld dim=%d",
              (long long)rows, dim);
     ProfScope prof(stream, "layernorm_kernel", 0.0, (double)rows * dim * (4 + (y16 ? 2 : 0) + (y32 ? 4 : 0)));
-    ME_BY_DTYPE(dtype, layernorm_typed<f16>(x, w, b, y16, y32, rows, dim, eps, stream),
-                layernorm_typed<bf16>(x, w, b, y16, y32, rows, dim, eps, stream));
+    ME_BY_DTYPE(dtype, layernorm_typed<f16>(x, w, b, y16, y32, rows, dim, eps, stream, segs),
+                layernorm_typed<bf16>(x, w, b, y16, y32, rows, dim, eps, stream, segs));
 }
 
 void preprocess_u8_launch(const uint8_t* rgb, float* img, int32_t batch, int32_t size,

@@ -74,13 +74,13 @@ static bool dynamic_tile_order() {
     return on;
 }
 
-static int pick_config(int64_t M, int64_t N, int64_t K) {
+static int pick_config(int64_t M, int64_t N, int64_t K, int64_t seg1, int64_t seg2) {
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
     if (N < 128 || t1 < 256) {
         // few 64x64 tiles and a long K (the M = 577 fc2: 160 tiles x 64 slabs): the six-slot ring keeps
         // five slabs in flight (33 -> 19 us); with many tiles its 96 KiB of LDS per workgroup costs more
         // in occupancy than the latency it hides
-        return cdiv(M, 64) * cdiv(N, 64) <= 256 && K >= 2048 ? CFG_RING64 : CFG_64;
+        return cdiv(M, 64) * cdiv(N, 64) <= 512 && K >= 2048 ? CFG_RING64 : CFG_64;
     }
     struct Cand {
         int cfg, bm, bn, per_cu;
@@ -91,6 +91,7 @@ static int pick_config(int64_t M, int64_t N, int64_t K) {
     double best_cost = 0.0;
     for (const Cand& c : cands) {
         if (N < c.bn || (c.cfg == CFG_PP256 && K < 128)) continue;
+        if (seg1 % c.bm || seg2 % c.bm) continue;  // row segments must start on tile boundaries
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         // static order: whole rounds; dynamic order: workgroups draw tiles until none are left, so the
         // launch takes the average share plus about half a tile of tail
@@ -162,8 +163,14 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
-    int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K);
+    int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K, p.seg1, p.seg2);
     if (cfg == CFG_PP256 && p.K < 128) cfg = CFG_128;  // the two-group kernel prefetches two slabs ahead
+    {
+        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64};
+        const int bm = epi == EPI_HEAD_FINAL ? 256 : kTileRows[cfg];
+        ME_CHECK(p.seg1 % bm == 0 && p.seg2 % bm == 0 && (p.seg2 == 0 || p.seg2 > p.seg1), ME_ERR_BAD_ARG,
+                 "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);
+    }
     static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +

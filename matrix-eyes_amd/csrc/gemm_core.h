@@ -115,6 +115,15 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
+// Row segment of a tile (GemmParams::seg1 / seg2): tiles never straddle a segment boundary.
+__device__ __forceinline__ int row_segment(const GemmParams& p, int m0) {
+    return p.seg1 == 0 ? 0 : ((p.seg2 != 0 && m0 >= p.seg2) ? 2 : (m0 >= p.seg1 ? 1 : 0));
+}
+__device__ __forceinline__ const char* segment_weights(const GemmParams& p, int m0) {
+    const int g = row_segment(p, m0);
+    return (const char*)(g == 0 ? p.W : (g == 1 ? p.W_s1 : p.W_s2));
+}
+
 // Implicit-GEMM addressing shared by the three kernels.  Row m of the A operand is output pixel
 // (b, y, x); its K index is (tap, cin) with a 64-wide slab never straddling a tap (Cin % 64 == 0).
 // conv_pixel: element index / Cin of the tap-(0,0) source pixel of output row gm in the zero-bordered map.
@@ -391,13 +400,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             lc.co = n - lc.q * p.Cout;
         }
         if (n_ok) {
-            if (p.bias) {
-                lc.bias[0] = *reinterpret_cast<const float4*>(p.bias + lc.co);
-                if (hi_ok) lc.bias[1] = *reinterpret_cast<const float4*>(p.bias + lc.co + 4);
+            const int seg = row_segment(p, m0);
+            const float* bias = seg == 0 ? p.bias : (seg == 1 ? p.bias_s1 : p.bias_s2);
+            if (bias) {
+                lc.bias[0] = *reinterpret_cast<const float4*>(bias + lc.co);
+                if (hi_ok) lc.bias[1] = *reinterpret_cast<const float4*>(bias + lc.co + 4);
             }
             if constexpr (EPI == EPI_RESID_SCALE) {
-                lc.gamma[0] = *reinterpret_cast<const float4*>(p.gamma + n);
-                if (hi_ok) lc.gamma[1] = *reinterpret_cast<const float4*>(p.gamma + n + 4);
+                const float* gamma = seg == 0 ? p.gamma : (seg == 1 ? p.gamma_s1 : p.gamma_s2);
+                lc.gamma[0] = *reinterpret_cast<const float4*>(gamma + n);
+                if (hi_ok) lc.gamma[1] = *reinterpret_cast<const float4*>(gamma + n + 4);
             }
         }
         after_loads();
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
             const int chunk = sslot ^ ((row >> 1) & 7);
             int gn = t.n0 + row;
             gn = gn < p.N ? gn : p.N - 1;
-            t.w[i] = (const char*)p.W + ((int64_t)gn * p.K) * 2 + chunk * 16;
+            t.w[i] = segment_weights(p, t.m0) + ((int64_t)gn * p.K) * 2 + chunk * 16;
         }
     };
 
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                 t.s[i] = (unsigned)((el - base_el) * 2) + chunk * 16;
             }
         } else {
-            t.base = (const char*)p.W + (int64_t)t.n0 * p.K * 2;
+            t.base = segment_weights(p, t.m0) + (int64_t)t.n0 * p.K * 2;
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
                 const int row = (i * HW + gw) * 8 + srow;
@@ -1106,7 +1118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams
     else
         a_base_el = pixel_of(m0) * p.Cin;
     const char* a_base = (const char*)p.A + a_base_el * 2;
-    const char* w_base = (const char*)p.W + (int64_t)n0 * p.K * 2;
+    const char* w_base = segment_weights(p, m0) + (int64_t)n0 * p.K * 2;
     unsigned a_off[A_IT], w_off[B_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {

@@ -87,6 +87,7 @@ struct me_ctx {
     // run on side streams beside the 35-window patch encoder.
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_img = nullptr, ev_fov = nullptr;
+    bool side_joined = false;  // this step's small ViTs ran on the launch stream: nothing to join
     std::string last_error;
     me_progress_fn progress = nullptr;
     void* progress_user = nullptr;

@@ -221,6 +221,117 @@ struct VitRun {
         layernorm_launch(tok, v.norm_w, v.norm_b, final16, final32, rows, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s);
     }
 };
+
+// The encoder's three ViTs (patch encoder on 35 B windows, image encoder and FOV encoder on B windows each,
+// different weights, same architecture) as ONE row space: segment 0 = the patch encoder's rows, 1 = the
+// image encoder's, 2 = the FOV encoder's, each padded to a multiple of 256 rows so that no GEMM tile
+// straddles two weight sets.  Every kernel of a block then runs ONCE over all rows, with the weights chosen
+// per row tile (GEMMs, GemmParams::seg1/seg2), per row (LayerNorm) or not at all (attention: a window ->
+// row map).  qkv: 948 + 72 tiles still fit the four rounds the patch encoder needs alone; fc1 goes from
+// 4.94 to 5.31 rounds, which costs what the separate small launches did; proj / fc2 move to the 256x256
+// tile (see resid_all).  This replaces two side streams of ~170 small launches each, which took CUs from
+// the launch stream's persistent kernels at every kernel boundary (fc2 0.195 -> 0.34 ms on most layers):
+// 26.5 -> 25.5 ms per step, 580 -> 390 launches.
+struct MergedVit {
+    me_ctx* ctx;
+    const VitW &v0, &v1, &v2;
+    int W0, W1;        // windows of segment 0 and of each small segment
+    bool fov;
+    VitTaps taps;
+    hipStream_t s;
+    int64_t R0, seg1, seg2, Rtot;  // seg2 == 0 without the FOV encoder
+    float* tok;
+    char *xn, *qkv, *att, *hid, *fin16;
+    RowSegs segs;
+
+    static int64_t pad256(int64_t r) { return (r + 255) / 256 * 256; }
+
+    MergedVit(me_ctx* ctx_, int B, bool fov_, const void* patches_main, const void* patches_img,
+              const void* patches_fov, const VitTaps& taps_, hipStream_t s_)
+        : ctx(ctx_), v0(ctx_->w.vit[ME_VIT_PATCH_ENCODER]), v1(ctx_->w.vit[ME_VIT_IMAGE_ENCODER]),
+          v2(ctx_->w.vit[ME_VIT_FOV_ENCODER]), W0(35 * B), W1(B), fov(fov_), taps(taps_), s(s_) {
+        const int C = ctx->C(), T = ctx->T(), P = ctx->P();
+        R0 = (int64_t)W0 * T;
+        seg1 = pad256(R0);
+        const int64_t side = pad256((int64_t)W1 * T);
+        seg2 = fov ? seg1 + side : 0;
+        Rtot = seg1 + side * (fov ? 2 : 1);
+        tok = (float*)site_buf(ctx, "vitm.tokens", (size_t)Rtot * C * 4);
+        xn = (char*)site_buf(ctx, "vitm.xn", (size_t)Rtot * C * 2);
+        qkv = (char*)site_buf(ctx, "vitm.qkv", (size_t)Rtot * 3 * C * 2);
+        att = (char*)site_buf(ctx, "vitm.att", (size_t)Rtot * C * 2);
+        hid = (char*)site_buf(ctx, "vitm.hid", (size_t)Rtot * 4 * C * 2);
+        fin16 = (char*)site_buf(ctx, "vitm.final16", (size_t)Rtot * C * 2);
+        segs.seg1 = seg1, segs.seg2 = seg2, segs.win0 = W0, segs.win1 = W1;
+        // vit.rs:287-295 per ViT: patch embed + cls + pos into its segment
+        embed(v0, patches_main, W0, 0);
+        embed(v1, patches_img, W1, seg1);
+        if (fov) embed(v2, patches_fov, W1, seg2);
+        (void)P;
+    }
+
+    void embed(const VitW& v, const void* patches16, int W, int64_t row) {
+        const int C = ctx->C(), T = ctx->T(), P = ctx->P();
+        cls_rows_launch(tok + row * C, v.cls, v.pos, W, T, C, s);
+        GemmParams p = base_params();
+        p.M = W * P, p.N = C, p.K = 768, p.A = patches16, p.lda = 768, p.W = v.patch_w;
+        p.bias = v.patch_b, p.pos = v.pos, p.out32 = tok + row * C, p.ldc = C, p.tokens_per_window = P;
+        gemm_launch(p, A_PLAIN, EPI_PATCH_EMBED, ctx->dtype, s);
+    }
+
+    void set_ln(const float* w1, const float* b1, const float* w2, const float* b2) {
+        segs.w1 = w1, segs.b1 = b1, segs.w2 = w2, segs.b2 = b2;
+    }
+
+    // one GEMM over all segments (three weight sets): 16-bit output (qkv, fc1) ...
+    void gemm_all(const void* A, int K, const void* w0, const void* w1, const void* w2, const float* b0,
+                  const float* b1, const float* b2, int N, void* out16, int act) {
+        GemmParams p = base_params();
+        p.M = (int)Rtot, p.N = N, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = b0;
+        p.out16 = out16, p.ldc = N, p.act = act;
+        p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = b1, p.W_s2 = w2, p.bias_s2 = b2;
+        gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
+    }
+    // ... or the residual update x += gamma * (A W^T + b) (proj, fc2).  On the two-group 256x256 tile: the
+    // patch encoder's rows alone take 160x128 (two exact rounds), but with the small segments' 24 tiles more
+    // the 340 tiles of 256x256 (two rounds) win: 25.5 vs 26.0 ms per step against separate launches.
+    void resid_all(const char* A, int K, const void* w0, const float* bb0, const float* g0, const void* w1,
+                   const float* bb1, const float* g1, const void* w2, const float* bb2, const float* g2) {
+        const int C = ctx->C();
+        GemmParams p = base_params();
+        p.M = (int)Rtot, p.N = C, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = bb0, p.gamma = g0;
+        p.res32 = tok, p.out32 = tok, p.ldc = C;
+        p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = bb1, p.gamma_s1 = g1;
+        p.W_s2 = w2, p.bias_s2 = bb2, p.gamma_s2 = g2;
+        // tile configuration 0 = the two-group 256x256 kernel (the cost model rates 128x128 a hair cheaper
+        // here; measured it is not)
+        gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, C >= 256 && K >= 128 ? 0 : -1);
+    }
+
+    // vit.rs:163-170 Block::forward for the three ViTs
+    void block(int i) {
+        const VitBlockW &b0 = v0.blocks[i], &b1 = v1.blocks[i], &b2 = v2.blocks[i];
+        const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
+        set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
+        layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE);
+        attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
+        resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
+        set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
+        layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        gemm_all(xn, C, b0.fc1_w, b1.fc1_w, b2.fc1_w, b0.fc1_b, b1.fc1_b, b2.fc1_b, 4 * C, hid, ACT_GELU);
+        resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2);
+        if (taps.fn) taps.fn(taps.user, i, tok);
+    }
+
+    // vit.rs:343 final norm of each ViT; the 16-bit results of segments 0 / 1 / 2
+    void finish() {
+        set_ln(v1.norm_w, v1.norm_b, v2.norm_w, v2.norm_b);
+        layernorm_launch(tok, v0.norm_w, v0.norm_b, fin16, nullptr, Rtot, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s,
+                         &segs);
+    }
+    void* final16(int seg) const { return fin16 + (seg == 0 ? 0 : (seg == 1 ? seg1 : seg2)) * ctx->C() * 2; }
+};
 }  // namespace
 
 void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
@@ -265,12 +376,31 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     // block by block in turn: the side chains are the last thing the decoder waits for, so they must not
     // start a whole patch-encoder's worth of host launches late, and the launch stream must not sit empty
     // while ~350 small side launches are issued either (it did: 3.8 ms of the step in a rocprofv3 trace).
+    static const bool side_streams = getenv("ME_SIDE_STREAMS") != nullptr;  // the earlier arrangement
+    ctx->side_joined = !side_streams;
+    void* tokg16 = nullptr;
+    void* fov_tok16 = nullptr;
+    if (!side_streams) {
+        // one row space for the three ViTs on the launch stream (MergedVit above)
+        void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
+        patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s);  // both small ViTs embed the same patches
+        if (fov_async) report(ctx, 0.03f, "encoding fov");
+        MergedVit run(ctx, B, fov_async, patches, patches2, patches2, taps, s);
+        for (int i = 0; i < c.depth; ++i) run.block(i);
+        run.finish();
+        tok16 = run.final16(0), tokg16 = run.final16(1), fov_tok16 = fov_async ? run.final16(2) : nullptr;
+        merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s);
+        if (fov_async) {
+            float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
+            linear(ctx, fov_tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
+                   dec / 2, ACT_NONE, s);
+        }
+    } else {
     hipStream_t s1 = ctx->side[0], s2 = ctx->side[1];
     ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
     void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
     patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
-    void* tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
-    void* fov_tok16 = nullptr;
+    tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
     if (fov_async) {  // stage_fov_vit, issued in step with the others
         ME_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
         report(ctx, 0.03f, "encoding fov");
@@ -301,6 +431,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
                dec / 2, ACT_NONE, s2);
         ME_HIP(hipEventRecord(ctx->ev_fov, s2));
     }
+    }
     report(ctx, 0.55f, "reshaping patch encodings");
     // encoder.rs:263,285-294: split_with_sizes + merge
     void* x0f = site_buf(ctx, "enc.x0f", (size_t)B * side0 * side0 * C * 2);
@@ -328,7 +459,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     char* cat = (char*)site_buf(ctx, "enc.cat", (size_t)B * H4 * H4 * 2 * e3 * 2);
     run_upsample(ctx, "up2", x2f, B, g, ctx->w.up2, nullptr, cat, false, 2 * e3, ACT_NONE, s);
     report(ctx, 0.9f, "upsampling lowres");
-    ME_HIP(hipStreamWaitEvent(s, ctx->ev_img, 0));  // join the image encoder
+    if (!ctx->side_joined) ME_HIP(hipStreamWaitEvent(s, ctx->ev_img, 0));  // join the image encoder
     convt(ctx, xg, B, g, g, C, ctx->w.up_lowres_w, e3, ctx->w.up_lowres_b, nullptr, cat + (size_t)e3 * 2,
           false, 2 * e3, ACT_NONE, s);
     report(ctx, 0.95f, "fusing lowres");
@@ -475,7 +606,7 @@ void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev, bool join_side_strea
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), P = ctx->P(), T = ctx->T(), dec = c.dec_dim;
-    if (join_side_stream) ME_HIP(hipStreamWaitEvent(s, ctx->ev_fov, 0));
+    if (join_side_stream && !ctx->side_joined) ME_HIP(hipStreamWaitEvent(s, ctx->ev_fov, 0));
     report(ctx, 0.85f, "fov lowres");
     const float* lin32 = (const float*)ctx->bufs.at("fov.lin").p;
     // fov.rs:70-74: relu(downsample[0](lowres)) + reshaped tokens
