@@ -45,21 +45,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 // Phi(x) * x with the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121).
-// erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), evaluated on |x| so the negative
-// tail keeps its relative accuracy.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp), not the
-                                                                    // 10-instruction IEEE division
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    poly *= t;
-    const float e = poly * __expf(-z * z);  // erfc(z)
-    const float phi = x < 0.0f ? 0.5f * e : 1.0f - 0.5f * e;
-    return x * phi;
+// erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), evaluated on |x| so the negative tail keeps its
+// relative accuracy: with z = |x| / sqrt(2), h = erfc(z) / 2 = poly(t) exp(-z^2), t = 1 / (1 + p z), the
+// result is max(x, 0) - |x| h for either sign.  Two values at a time: the multiplies and FMAs are
+// v_pk_*_f32, v_rcp_f32 (1 ulp, not the 10-instruction IEEE division) and v_exp_f32 stay per value; the
+// constants carry the 1/sqrt(2), the 1/2 and the log2(e).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 den = ax * 0.23164189f + 1.0f;  // 0.3275911 / sqrt(2)
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 poly = t * 0.5307027145f - 0.7265760135f;  // the A-S coefficients halved
+    poly = poly * t + 0.7107068705f;
+    poly = poly * t - 0.142248368f;
+    poly = poly * t + 0.127414796f;
+    poly = poly * t;
+    const f32x2 arg = (x * -0.72134752f) * x;  // -z^2 log2(e)
+    const f32x2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    const f32x2 h = poly * ex;
+    const f32x2 pos = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+    return pos - h * ax;
 }
 
 template <typename T>
@@ -236,8 +241,8 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
             if constexpr (MODE == 2) {
-                a[4 * h] = gelu_erf(x0), a[4 * h + 1] = gelu_erf(x1);
-                a[4 * h + 2] = gelu_erf(x2), a[4 * h + 3] = gelu_erf(x3);
+                const f32x2 g0 = gelu_erf2(f32x2{x0, x1}), g1 = gelu_erf2(f32x2{x2, x3});
+                a[4 * h] = g0.x, a[4 * h + 1] = g0.y, a[4 * h + 2] = g1.x, a[4 * h + 3] = g1.y;
             } else {
                 a[4 * h] = x0, a[4 * h + 1] = x1, a[4 * h + 2] = x2, a[4 * h + 3] = x3;
             }
@@ -260,7 +265,8 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             }
             float a0 = x0, a1 = x1, a2 = x2, a3 = x3;
             if (p.act == ACT_GELU) {
-                a0 = gelu_erf(x0), a1 = gelu_erf(x1), a2 = gelu_erf(x2), a3 = gelu_erf(x3);
+                const f32x2 g0 = gelu_erf2(f32x2{x0, x1}), g1 = gelu_erf2(f32x2{x2, x3});
+                a0 = g0.x, a1 = g0.y, a2 = g1.x, a3 = g1.y;
             } else if (p.act == ACT_RELU) {
                 a0 = fmaxf(x0, 0.f), a1 = fmaxf(x1, 0.f), a2 = fmaxf(x2, 0.f), a3 = fmaxf(x3, 0.f);
             }
