@@ -44,27 +44,37 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// Phi(x) * x with the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121).
-// erfc via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), evaluated on |x| so the negative tail keeps its
-// relative accuracy: with z = |x| / sqrt(2), h = erfc(z) / 2 = poly(t) exp(-z^2), t = 1 / (1 + p z), the
-// result is max(x, 0) - |x| h for either sign.  Two values at a time: the multiplies and FMAs are
-// v_pk_*_f32, v_rcp_f32 (1 ulp, not the 10-instruction IEEE division) and v_exp_f32 stay per value; the
-// constants carry the 1/sqrt(2), the 1/2 and the log2(e).
+// x * Phi(x), the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121), as
+// max(x, 0) - a * Phi(-a) with a = |x|: the lower tail Phi(-a) = erfc(a / sqrt 2) / 2 keeps its relative
+// accuracy for either sign.  log2 Phi(-a) is smooth and nearly quadratic, so a degree-9 polynomial on
+// [0, 5.5] (Chebyshev fit; beyond 5.5 a * Phi(-a) < 1.1e-7) followed by ONE v_exp_f32 reproduces it to
+// 7e-7 relative: |error of the result| <= 2.4e-7 over [-8, 8], which is the f32 rounding of the result
+// itself (the Abramowitz-Stegun 7.1.26 form used before: 2.1e-7, with a v_rcp_f32 besides the exponential;
+// transcendentals were half of the epilogue's arithmetic).  Four values at a time: the Horner steps are
+// v_pk_fma_f32.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
-    const f32x2 den = ax * 0.23164189f + 1.0f;  // 0.3275911 / sqrt(2)
-    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-    f32x2 poly = t * 0.5307027145f - 0.7265760135f;  // the A-S coefficients halved
-    poly = poly * t + 0.7107068705f;
-    poly = poly * t - 0.142248368f;
-    poly = poly * t + 0.127414796f;
-    poly = poly * t;
-    const f32x2 arg = (x * -0.72134752f) * x;  // -z^2 log2(e)
-    const f32x2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-    const f32x2 h = poly * ex;
-    const f32x2 pos = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
-    return pos - h * ax;
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
+    // v_med3_f32 for the clamps: fminf / fmaxf cost a canonicalising v_max_f32 each on top
+    auto clamp_abs = [](float v) { return __builtin_amdgcn_fmed3f(fabsf(v), 0.0f, 5.5f); };
+    auto positive = [](float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); };
+    const f32x2 a0 = {clamp_abs(x[0]), clamp_abs(x[1])}, a1 = {clamp_abs(x[2]), clamp_abs(x[3])};
+    const f32x2 p0 = {positive(x[0]), positive(x[1])}, p1 = {positive(x[2]), positive(x[3])};
+    // two independent v_pk_fma_f32 chains, step by step (a dependent v_pk_fma_f32 costs a wait state)
+    f32x2 q0 = a0 * 7.329674645e-08f - 1.913058668e-06f, q1 = a1 * 7.329674645e-08f - 1.913058668e-06f;
+#define ME_GELU_STEP(c) q0 = q0 * a0 + (c), q1 = q1 * a1 + (c)
+    ME_GELU_STEP(1.896382855e-05f);
+    ME_GELU_STEP(-6.020677392e-05f);
+    ME_GELU_STEP(-5.156729021e-04f);
+    ME_GELU_STEP(7.680844516e-03f);
+    ME_GELU_STEP(-5.303888768e-02f);
+    ME_GELU_STEP(-4.589743018e-01f);
+    ME_GELU_STEP(-1.151143670e+00f);
+    ME_GELU_STEP(-9.999989867e-01f);
+#undef ME_GELU_STEP
+    const f32x2 h0 = {__builtin_amdgcn_exp2f(q0.x), __builtin_amdgcn_exp2f(q0.y)};  // Phi(-a)
+    const f32x2 h1 = {__builtin_amdgcn_exp2f(q1.x), __builtin_amdgcn_exp2f(q1.y)};
+    const f32x2 r0 = p0 - h0 * a0, r1 = p1 - h1 * a1;
+    return f32x4{r0.x, r0.y, r1.x, r1.y};
 }
 
 template <typename T>
@@ -241,8 +251,8 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
             if constexpr (MODE == 2) {
-                const f32x2 g0 = gelu_erf2(f32x2{x0, x1}), g1 = gelu_erf2(f32x2{x2, x3});
-                a[4 * h] = g0.x, a[4 * h + 1] = g0.y, a[4 * h + 2] = g1.x, a[4 * h + 3] = g1.y;
+                const f32x4 g = gelu_erf4(f32x4{x0, x1, x2, x3});
+                a[4 * h] = g[0], a[4 * h + 1] = g[1], a[4 * h + 2] = g[2], a[4 * h + 3] = g[3];
             } else {
                 a[4 * h] = x0, a[4 * h + 1] = x1, a[4 * h + 2] = x2, a[4 * h + 3] = x3;
             }
@@ -265,8 +275,8 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             }
             float a0 = x0, a1 = x1, a2 = x2, a3 = x3;
             if (p.act == ACT_GELU) {
-                const f32x2 g0 = gelu_erf2(f32x2{x0, x1}), g1 = gelu_erf2(f32x2{x2, x3});
-                a0 = g0.x, a1 = g0.y, a2 = g1.x, a3 = g1.y;
+                const f32x4 g = gelu_erf4(f32x4{x0, x1, x2, x3});
+                a0 = g[0], a1 = g[1], a2 = g[2], a3 = g[3];
             } else if (p.act == ACT_RELU) {
                 a0 = fmaxf(x0, 0.f), a1 = fmaxf(x1, 0.f), a2 = fmaxf(x2, 0.f), a3 = fmaxf(x3, 0.f);
             }

@@ -8,7 +8,7 @@ from tools.bench_kernels import ptr
 ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 lib.me_debug_set_stamps.argtypes = [C.c_void_p]
-M = 35 * 577
+M = int(os.environ.get("STAMPS_M", 35 * 577))
 for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", 0)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     bias = torch.randn(N, device="cuda"); out16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
