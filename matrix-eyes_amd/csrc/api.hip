@@ -601,6 +601,7 @@ int32_t me_op_linear_residual(me_ctx* ctx, int32_t M, int32_t N, int32_t K, cons
     ME_API_BEGIN(ctx)
     ME_CHECK(bias && gamma && x32, ME_ERR_BAD_ARG, "me_op_linear_residual: null pointer");
     GemmParams p = GemmParams();
+    p.stamps = g_stamps;
     p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16, p.bias = bias, p.gamma = gamma;
     p.res32 = x32, p.out32 = x32, p.ldc = N;
     gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, ctx->stream, tile_cfg);

@@ -40,7 +40,7 @@ def main():
     res = []
     M = 35 * 577
     for (N, K, name) in [(3072, 1024, "qkv"), (1024, 1024, "proj"), (4096, 1024, "fc1"), (1024, 4096, "fc2")]:
-        for Mx in (577, M, 4 * M):
+        for Mx in (577, M, 21760, 4 * M):   # 21760 = the merged rows of the three ViTs at one image
             a = torch.randn(Mx, K, device="cuda").to(t16)
             w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(t16)
             bias = torch.randn(N, device="cuda")

@@ -9,14 +9,19 @@ ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 lib.me_debug_set_stamps.argtypes = [C.c_void_p]
 M = int(os.environ.get("STAMPS_M", 35 * 577))
-for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", 0)]:
+for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", 0), (1024, 1024, "proj-resid", 0), (1024, 4096, "fc2-resid", 0)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     bias = torch.randn(N, device="cuda"); out16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
     for it in range(3):
         stamps.zero_()
         lib.me_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
-        rc = lib.me_op_linear(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(out16), None, 1 if name == "fc1" else 0, cfg)
+        if name.endswith("resid"):
+            if it == 0:
+                x32 = torch.randn(M, N, device="cuda"); gamma = torch.rand(N, device="cuda")
+            rc = lib.me_op_linear_residual(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x32), cfg)
+        else:
+            rc = lib.me_op_linear(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(out16), None, 1 if name == "fc1" else 0, cfg)
         if rc: print("rc", rc, lib.me_last_error(h))
         ctx.synchronize()
     lib.me_debug_set_stamps(None)
