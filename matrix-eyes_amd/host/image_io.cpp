@@ -36,7 +36,7 @@ int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path) {
+RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path, std::vector<uint8_t>* exif) {
     size_t pos = 8;
     uint32_t width = 0, height = 0;
     int depth = 0, ctype = -1, interlace = 0;
@@ -52,6 +52,8 @@ RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path) {
             depth = body[8], ctype = body[9], interlace = body[12];
         } else if (!std::memcmp(type, "PLTE", 4)) {
             plte.assign(body, body + len);
+        } else if (!std::memcmp(type, "eXIf", 4)) {
+            if (exif) exif->assign(body, body + len);
         } else if (!std::memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), body, body + len);
         } else if (!std::memcmp(type, "IEND", 4)) {
@@ -215,11 +217,90 @@ void resample(const std::vector<float>& in, std::vector<float>& out, uint32_t le
 
 }  // namespace
 
-RgbImage load_image(const std::string& path) {
+// ---- EXIF ---------------------------------------------------------------------------------------------
+// TIFF structure: byte order mark, offset of IFD0; 12-byte entries (tag, type, count, value / offset).
+// Orientation (0x0112) lives in IFD0, FocalLengthIn35mmFilm (0xA405) in the Exif sub-IFD (0x8769).
+ImageMetadata parse_exif(const std::vector<uint8_t>& e) {
+    ImageMetadata m;
+    if (e.size() < 8) return m;
+    const bool le = e[0] == 'I' && e[1] == 'I';
+    if (!le && !(e[0] == 'M' && e[1] == 'M')) return m;
+    auto u16 = [&](size_t p) -> uint32_t { return p + 2 <= e.size() ? (le ? e[p] | (e[p + 1] << 8) : (e[p] << 8) | e[p + 1]) : 0u; };
+    auto u32 = [&](size_t p) -> uint32_t {
+        if (p + 4 > e.size()) return 0u;
+        return le ? (uint32_t)e[p] | (e[p + 1] << 8) | (e[p + 2] << 16) | ((uint32_t)e[p + 3] << 24)
+                  : ((uint32_t)e[p] << 24) | (e[p + 1] << 16) | (e[p + 2] << 8) | e[p + 3];
+    };
+    if (u16(2) != 42) return m;
+    // value of an entry as an unsigned integer (BYTE, SHORT or LONG, first element)
+    auto entry_uint = [&](size_t p, uint32_t* out) {
+        const uint32_t type = u16(p + 2), count = u32(p + 4);
+        if (count < 1) return false;
+        if (type == 1) *out = e[p + 8];
+        else if (type == 3) *out = u16(p + 8);
+        else if (type == 4) *out = u32(p + 8);
+        else return false;
+        return true;
+    };
+    auto walk = [&](size_t ifd, auto&& on_entry) {
+        if (ifd == 0 || ifd + 2 > e.size()) return;
+        const uint32_t n = u16(ifd);
+        for (uint32_t i = 0; i < n; ++i) {
+            const size_t p = ifd + 2 + 12 * (size_t)i;
+            if (p + 12 > e.size()) return;
+            on_entry(u16(p), p);
+        }
+    };
+    size_t exif_ifd = 0;
+    walk(u32(4), [&](uint32_t tag, size_t p) {
+        uint32_t v;
+        if (tag == 0x0112 && entry_uint(p, &v) && v >= 1 && v <= 8) m.orientation = (int)v;
+        if (tag == 0x8769 && entry_uint(p, &v)) exif_ifd = v;
+        if (tag == 0xa405 && entry_uint(p, &v)) m.focal_length_35mm = v;
+    });
+    walk(exif_ifd, [&](uint32_t tag, size_t p) {
+        uint32_t v;
+        if (tag == 0xa405 && entry_uint(p, &v)) m.focal_length_35mm = v;
+    });
+    return m;
+}
+
+RgbImage apply_orientation(const RgbImage& img, int orientation) {
+    if (orientation <= 1 || orientation > 8) return img;
+    const uint32_t w = img.width, h = img.height;
+    const bool swap = orientation >= 5;
+    RgbImage out(swap ? h : w, swap ? w : h);
+    for (uint32_t y = 0; y < out.height; ++y)
+        for (uint32_t x = 0; x < out.width; ++x) {
+            uint32_t sx, sy;  // source pixel of output (x, y)
+            switch (orientation) {
+                case 2: sx = w - 1 - x, sy = y; break;          // flip horizontally
+                case 3: sx = w - 1 - x, sy = h - 1 - y; break;  // rotate 180
+                case 4: sx = x, sy = h - 1 - y; break;          // flip vertically
+                case 5: sx = y, sy = x; break;                  // transpose
+                case 6: sx = y, sy = h - 1 - x; break;          // rotate 90 clockwise
+                case 7: sx = w - 1 - y, sy = h - 1 - x; break;  // transverse
+                default: sx = w - 1 - y, sy = x; break;         // 8: rotate 270 clockwise
+            }
+            std::memcpy(&out.data[((size_t)y * out.width + x) * 3], &img.data[((size_t)sy * w + sx) * 3], 3);
+        }
+    return out;
+}
+
+RgbImage load_image(const std::string& path, ImageMetadata* metadata) {
     const std::vector<uint8_t> file = read_file(path);
-    if (file.size() >= 8 && !std::memcmp(file.data(), kPngSig, 8)) return decode_png(file, path);
-    if (file.size() >= 2 && file[0] == 'P' && file[1] == '6') return decode_ppm(file, path);
-    throw ImageError(path + ": unsupported image format (this host layer decodes PNG and binary PPM)");
+    std::vector<uint8_t> exif;
+    RgbImage img;
+    if (file.size() >= 8 && !std::memcmp(file.data(), kPngSig, 8))
+        img = decode_png(file, path, &exif);
+    else if (file.size() >= 3 && file[0] == 0xff && file[1] == 0xd8 && file[2] == 0xff)
+        img = decode_jpeg(file, path, &exif);
+    else if (file.size() >= 2 && file[0] == 'P' && file[1] == '6')
+        img = decode_ppm(file, path);
+    else
+        throw ImageError(path + ": unsupported image format (this host layer decodes JPEG, PNG and binary PPM)");
+    if (metadata) *metadata = parse_exif(exif);
+    return img;
 }
 
 void save_image(const RgbImage& img, const std::string& path) {

@@ -203,14 +203,16 @@ struct ProgressReporter : ProgressListener {
 SourceImage SourceImage::load(const std::string& path, std::optional<float> focal_length_35mm, int size) {
     SourceImage s;
     RgbImage img;
+    ImageMetadata meta;
     try {
-        img = load_image(path);
+        img = load_image(path, &meta);
     } catch (const ImageError& err) {
         throw ReconstructionError(std::string("Image error: ") + err.what());
     }
-    // PNG and PPM carry no EXIF block this layer reads: the focal length is the caller's or absent
-    // (reconstruction.rs:97-103), the orientation is the identity (:104-105)
+    // reconstruction.rs:97-103: the caller's focal length wins, else EXIF FocalLengthIn35mmFilm, else none
     s.focal_length_35mm = focal_length_35mm;
+    if (!s.focal_length_35mm && meta.focal_length_35mm) s.focal_length_35mm = (float)*meta.focal_length_35mm;
+    img = apply_orientation(img, meta.orientation);  // :104-106
     s.original_width = img.width, s.original_height = img.height;
     s.img = resize_exact_lanczos3(img, (uint32_t)size, (uint32_t)size);
     return s;

@@ -2,6 +2,8 @@
 //   host_selftest pt <checkpoint.pt>            one line per tensor: name dtype dims... fnv1a64(data)
 //   host_selftest png <in> <out>                decode, re-encode
 //   host_selftest resize <in> <w> <h> <out>     Lanczos3 resize_exact
+//   host_selftest decode <in> <out> [oriented]  decode any supported format (optionally apply the EXIF
+//                                               orientation), write <out>; prints "orientation focal35 w h"
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +30,15 @@ int main(int argc, char** argv) {
             matrix_eyes::save_image(matrix_eyes::load_image(argv[2]), argv[3]);
             return 0;
         }
+        if ((argc == 4 || argc == 5) && !std::strcmp(argv[1], "decode")) {
+            matrix_eyes::ImageMetadata meta;
+            matrix_eyes::RgbImage img = matrix_eyes::load_image(argv[2], &meta);
+            if (argc == 5) img = matrix_eyes::apply_orientation(img, meta.orientation);
+            matrix_eyes::save_image(img, argv[3]);
+            std::printf("%d %ld %u %u\n", meta.orientation, meta.focal_length_35mm ? (long)*meta.focal_length_35mm : -1l,
+                        img.width, img.height);
+            return 0;
+        }
         if (argc == 6 && !std::strcmp(argv[1], "resize")) {
             matrix_eyes::save_image(matrix_eyes::resize_exact_lanczos3(matrix_eyes::load_image(argv[2]), (uint32_t)std::atoi(argv[3]),
                                                                        (uint32_t)std::atoi(argv[4])),
@@ -38,6 +49,6 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "error: %s\n", err.what());
         return 1;
     }
-    std::fprintf(stderr, "usage: host_selftest pt|png|resize ...\n");
+    std::fprintf(stderr, "usage: host_selftest pt|png|resize|decode ...\n");
     return 2;
 }

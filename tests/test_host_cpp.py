@@ -1,6 +1,6 @@
 """The C++ host layer (matrix-eyes_amd/host/): the compiled twin of the reference's main.rs /
 reconstruction.rs / DepthProModelLoader above the C ABI.  CPU part: checkpoint reader against torch, PNG
-codec and Lanczos3 against Pillow, CLI usage and exit codes.  GPU part (-m gpu): the CLI end to end on the
+codec, JPEG decoder, EXIF and Lanczos3 against Pillow, CLI usage and exit codes.  GPU part (-m gpu): the CLI end to end on the
 test geometry, against the Python mirror driving the same library."""
 import os
 import subprocess
@@ -87,6 +87,83 @@ def test_lanczos3_against_pillow(tmp_path, size):
     assert got.shape == want.shape and np.abs(got - want).max() <= 1     # one code of rounding at most
 
 
+def _photo(w, h, seed):
+    """a smooth, noisy, colourful picture: what JPEG is made for"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([127 + 100 * np.sin(x / 17.0 + y / 29.0), 127 + 100 * np.cos(x / 11.0 - y / 23.0),
+                  127 + 90 * np.sin((x + y) / 31.0)], -1) + rng.normal(0, 6, (h, w, 3))
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def _decode(src, dst, oriented=False):
+    r = subprocess.run([SELFTEST, "decode", src, dst] + (["oriented"] if oriented else []), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from PIL import Image
+    return np.asarray(Image.open(dst)).astype(int), [int(v) for v in r.stdout.split()]
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])          # 4:4:4, 4:2:2, 4:2:0
+@pytest.mark.parametrize("size", [(123, 77), (64, 48), (1, 19), (3, 2)])
+def test_jpeg_decoder_against_pillow(tmp_path, size, subsampling, progressive):
+    """reconstruction.rs:96,106: the source photo is usually a JPEG.  Two conforming decoders differ by IDCT
+    and colour rounding: within 3 codes per sample and 0.1 on average of libjpeg-turbo (Pillow)."""
+    from PIL import Image
+    for k, quality in enumerate((95, 55)):
+        src, dst = str(tmp_path / f"in{k}.jpg"), str(tmp_path / f"out{k}.ppm")
+        Image.fromarray(_photo(*size, seed=3)).save(src, quality=quality, subsampling=subsampling,
+                                                     progressive=progressive, optimize=bool(k))
+        got, meta = _decode(src, dst)
+        want = np.asarray(Image.open(src).convert("RGB")).astype(int)
+        assert got.shape == want.shape and meta == [1, -1, size[0], size[1]]
+        d = np.abs(got - want)
+        assert d.max() <= 3 and (d.mean() < 0.1 or d.size < 3000), (d.max(), d.mean())   # a few pixels have no average
+
+
+def test_jpeg_grey_restart_intervals_and_errors(tmp_path):
+    from PIL import Image
+    src, dst = str(tmp_path / "g.jpg"), str(tmp_path / "g.ppm")
+    Image.fromarray(_photo(100, 60, seed=4)).convert("L").save(src, quality=90)
+    got, _ = _decode(src, dst)
+    assert np.abs(got - np.asarray(Image.open(src).convert("RGB")).astype(int)).max() <= 1
+    # restart markers every 2 MCU rows / every 5 MCUs (libjpeg's `restart_marker_rows / _blocks`)
+    for kw in ({"restart_marker_rows": 2}, {"restart_marker_blocks": 5}):
+        try:
+            Image.fromarray(_photo(203, 111, seed=5)).save(src, quality=85, **kw)
+        except TypeError:      # an older Pillow without the option
+            pytest.skip("Pillow cannot write restart markers")
+        assert b"\xff\xdd" in open(src, "rb").read()
+        got, _ = _decode(src, dst)
+        assert np.abs(got - np.asarray(Image.open(src).convert("RGB")).astype(int)).max() <= 3
+    cmyk = str(tmp_path / "cmyk.jpg")
+    Image.fromarray(_photo(32, 32, seed=6)).convert("CMYK").save(cmyk)
+    r = subprocess.run([SELFTEST, "decode", cmyk, dst], capture_output=True, text=True)
+    assert r.returncode == 1 and "4 components" in r.stderr
+    cut = str(tmp_path / "cut.jpg")
+    open(cut, "wb").write(open(src, "rb").read()[:300])
+    r = subprocess.run([SELFTEST, "decode", cut, dst], capture_output=True, text=True)
+    assert r.returncode in (0, 1)          # a truncated scan decodes to grey or is refused: never a crash
+
+
+@pytest.mark.parametrize("orientation", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("fmt", ["jpg", "png"])
+def test_exif_orientation_and_focal_length(tmp_path, orientation, fmt):
+    """reconstruction.rs:97-105,133-143: FocalLengthIn35mmFilm from the Exif IFD, the orientation applied to
+    the decoded pixels -- against Pillow's exif_transpose."""
+    from PIL import Image, ImageOps
+    img = Image.fromarray(_photo(48, 32, seed=7))
+    exif = Image.Exif()
+    exif[0x0112] = orientation
+    exif.get_ifd(0x8769)[0xA405] = 28            # FocalLengthIn35mmFilm lives in the Exif sub-IFD
+    src, dst = str(tmp_path / f"o.{fmt}"), str(tmp_path / "o.ppm")
+    img.save(src, exif=exif, **({"quality": 95, "subsampling": 0} if fmt == "jpg" else {}))
+    got, meta = _decode(src, dst, oriented=True)
+    want = np.asarray(ImageOps.exif_transpose(Image.open(src)).convert("RGB")).astype(int)
+    assert meta[:2] == [orientation, 28] and meta[2:] == [want.shape[1], want.shape[0]]
+    assert got.shape == want.shape and np.abs(got - want).max() <= (3 if fmt == "jpg" else 0)
+
+
 def test_cli_usage_and_exit_codes(tmp_path):
     r = subprocess.run([CLI, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "Usage: matrix-eyes [OPTIONS] <IMG_SRC>... <IMG_OUT>" in r.stdout
@@ -146,3 +223,31 @@ def test_cli_end_to_end_against_the_python_mirror(tmp_path):
     r = subprocess.run([CLI, f"--checkpoint-path={tmp_path / 'none.pt'}", src, str(tmp_path / "x.png")], env=env,
                        capture_output=True, text=True)
     assert r.returncode == 1 and "Reconstruction failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_jpeg_photo_with_exif(tmp_path):
+    """A rotated JPEG whose EXIF block carries the orientation and the 35 mm focal length: the CLI reads both
+    itself (no --focal-length), as reconstruction.rs:97-106 does.  The Python mirror decodes the same file with
+    libjpeg-turbo, whose samples differ by a code or two, so the depth maps agree closely, not bit for bit."""
+    from PIL import Image
+    import matrix_eyes_amd as m
+    from matrix_eyes_amd import reconstruction as R
+    cfg = m.ModelConfig.tiny()
+    ckpt = str(tmp_path / "tiny.pt")
+    _tiny_checkpoint(ckpt)
+    exif = Image.Exif()
+    exif[0x0112] = 6                                  # rotate 90 clockwise on display
+    exif.get_ifd(0x8769)[0xA405] = 50
+    src = str(tmp_path / "photo.jpg")
+    Image.fromarray(_photo(300, 200, seed=9)).save(src, quality=92, exif=exif)
+    env = dict(os.environ, MATRIX_EYES_MODEL="tiny")
+    r = subprocess.run([CLI, f"--checkpoint-path={ckpt}", src, str(tmp_path / "d_cpp.png")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    loader = m.DepthProModelLoader(ckpt, False, cfg)
+    R.extract_depth(0, loader, src, str(tmp_path / "d_py.png"), None, m.ImageOutputFormat.DepthMap(), m.VertexMode.Color)
+    a = np.asarray(Image.open(tmp_path / "d_cpp.png")).astype(int)
+    b = np.asarray(Image.open(tmp_path / "d_py.png")).astype(int)
+    assert a.shape == b.shape == (300, 200, 3)        # portrait after the rotation (height 300, width 200)
+    assert np.abs(a - b).mean() < 2.0
