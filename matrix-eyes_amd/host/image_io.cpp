@@ -62,6 +62,7 @@ RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path, s
         pos += 12 + len;
     }
     if (!width || !height || ctype < 0) throw ImageError(path + ": no IHDR");
+    if ((int64_t)width * height > kMaxPixels) throw ImageError(path + ": PNG larger than 2^28 pixels");
     if (interlace) throw ImageError(path + ": interlaced PNG is not supported");
     if (depth != 8 && depth != 16) throw ImageError(path + ": PNG bit depth " + std::to_string(depth) + " is not supported");
     int channels;
@@ -175,6 +176,7 @@ RgbImage decode_ppm(const std::vector<uint8_t>& file, const std::string& path) {
     const long w = next_int(), h = next_int(), maxv = next_int();
     ++pos;  // the single whitespace byte after maxval
     if (w <= 0 || h <= 0 || maxv != 255) throw ImageError(path + ": only 8-bit PPM is supported");
+    if ((int64_t)w * h > kMaxPixels) throw ImageError(path + ": PPM larger than 2^28 pixels");
     RgbImage img((uint32_t)w, (uint32_t)h);
     if (pos + img.data.size() > file.size()) throw ImageError(path + ": truncated PPM");
     std::memcpy(img.data.data(), &file[pos], img.data.size());

@@ -15,6 +15,8 @@ struct ImageError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+constexpr int64_t kMaxPixels = 1ll << 28;  // decoders refuse larger pictures instead of allocating for them
+
 struct RgbImage {  // image::RgbImage: row-major, 3 bytes per pixel
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> data;

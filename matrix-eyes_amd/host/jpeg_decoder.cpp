@@ -165,6 +165,7 @@ struct Decoder {
         height = be16(pos + 1), width = be16(pos + 3);
         const int n = file[pos + 5];
         if (!width || !height) fail("JPEG with zero size");
+        if ((int64_t)width * height > kMaxPixels) fail("JPEG larger than 2^28 pixels");
         if (n != 1 && n != 3) fail("JPEG with " + std::to_string(n) + " components is not supported");
         if (pos + 6 + 3 * (size_t)n > end) fail("bad SOF");
         comps.resize((size_t)n);

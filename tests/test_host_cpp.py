@@ -146,6 +146,41 @@ def test_jpeg_grey_restart_intervals_and_errors(tmp_path):
     assert r.returncode in (0, 1)          # a truncated scan decodes to grey or is refused: never a crash
 
 
+def test_image_decoders_survive_corrupt_files(tmp_path):
+    """Byte flips, deletions and truncations of JPEG / PNG files (with EXIF blocks): the decoders either decode
+    or report an ImageError -- exit code 0 or 1, never a signal.  (Run under ASan/UBSan during development.)"""
+    import random
+    from PIL import Image
+    rnd = random.Random(1)
+    img = Image.fromarray(_photo(56, 40, seed=8))
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    exif.get_ifd(0x8769)[0xA405] = 28
+    img.save(tmp_path / "s0.jpg", quality=90, subsampling=2, exif=exif)
+    img.save(tmp_path / "s1.jpg", quality=80, subsampling=1, progressive=True)
+    img.save(tmp_path / "s2.png", exif=exif)
+    img.convert("P").save(tmp_path / "s3.png")
+    seeds = [(tmp_path / n).read_bytes() for n in ("s0.jpg", "s1.jpg", "s2.png", "s3.png")]
+    codes = set()
+    for it in range(240):
+        b = bytearray(seeds[it % 4])
+        mode = rnd.random()
+        if mode < 0.7:
+            for _ in range(rnd.choice([1, 1, 2, 4, 8])):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif mode < 0.85:
+            i = rnd.randrange(len(b))
+            del b[i:i + rnd.randrange(1, 40)]
+        else:
+            b = b[:rnd.randrange(4, len(b))]
+        (tmp_path / "f.bin").write_bytes(bytes(b))
+        r = subprocess.run([SELFTEST, "decode", str(tmp_path / "f.bin"), str(tmp_path / "o.ppm"), "oriented"],
+                           capture_output=True, timeout=60)
+        assert r.returncode in (0, 1), (it, r.returncode, r.stderr[-300:])
+        codes.add(r.returncode)
+    assert codes == {0, 1}          # both outcomes occur: the corpus does exercise the error paths
+
+
 @pytest.mark.parametrize("orientation", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("fmt", ["jpg", "png"])
 def test_exif_orientation_and_focal_length(tmp_path, orientation, fmt):
