@@ -21,7 +21,7 @@ def main():
     ctx = m.Context(0, "f16", m.ModelConfig.tiny())
     lib, h = ctx.lib, ctx.handle
     t16 = torch.float16
-    M = 35 * 577
+    M = int(os.environ.get("PROBE_M", 21760))   # the merged rows of the three ViTs at one image (35 * 577 = one ViT)
     shapes = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
     if op in shapes:
         N, K = shapes[op]
@@ -45,6 +45,7 @@ def main():
         o32 = torch.empty(Hh * Hh, 256, device="cuda")
         f = lambda: lib.me_op_conv2d(h, ptr(xb), 1, Hh, Hh, 256, ptr(w), 256, 3, 1, ptr(bias), ptr(r32), None, ptr(o32), ptr(out16), 1, 2, 0, cfg)
     elif op == "attn":
+        M = 35 * 577
         qkv = torch.randn(M, 3072, device="cuda").to(t16)
         out = torch.empty(M, 1024, dtype=t16, device="cuda")
         f = lambda: lib.me_op_attention(h, ptr(qkv), ptr(out), 35, 577, 16)

@@ -22,7 +22,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
-DEFAULT = ["qkv:0", "fc1:0", "proj:3", "fc2:3", "conv768:0", "attn:0"]
+DEFAULT = ["qkv:0", "fc1:0", "proj:0", "fc2:0", "conv768:0", "attn:0"]
+CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6"}
+PROBE_M = 21760   # tools/gemm_probe.py's default rows
+SHAPES = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
+
+
+def describe(op, cfg):
+    """(kernel name as bench.py's profile reports it, algorithmic bytes per launch)"""
+    if op in SHAPES:
+        n, k = SHAPES[op]
+        resid = op in ("proj", "fc2")
+        out = PROBE_M * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
+        bytes_ = PROBE_M * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
+        return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
+    if op == "conv768":   # 16-bit bordered input, weights, f32 residual in, f32 + 16-bit out
+        px = 768 * 768
+        return f"gemm_kernel<f16,{CFG_NAMES[cfg]},conv,store>", 770 * 770 * 256 * 2 + 256 * 2304 * 2 + px * 256 * (4 + 4 + 2)
+    return "attention_kernel", 35 * 577 * (3072 + 1024) * 2
 KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_ring_kernel", "attention_kernel")
 
 
@@ -70,6 +87,7 @@ def main():
             entry["mfma_util"] = entry.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0)
             entry["clock_ghz"] = gui / entry["duration_us_under_pmc"] / 1e3
         entry["tile_config"] = int(cfg)
+        entry["bench_kernel"], entry["algorithmic_bytes"] = describe(op, int(cfg))
         result[op] = entry
     json.dump(result, open(out_json, "w"), indent=1)
     print(json.dumps(result, indent=1))
