@@ -46,16 +46,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // x * Phi(x), the exact-erf GELU the reference uses (burn activation::gelu, vit.rs:121), as
 // max(x, 0) - a * Phi(-a) with a = |x|: the lower tail Phi(-a) = erfc(a / sqrt 2) / 2 keeps its relative
-// accuracy for either sign.  log2 Phi(-a) is smooth and nearly quadratic, so a degree-9 polynomial on
-// [0, 5.5] (Chebyshev fit; beyond 5.5 a * Phi(-a) < 1.1e-7) followed by ONE v_exp_f32 reproduces it to
-// 7e-7 relative: |error of the result| <= 2.4e-7 over [-8, 8], which is the f32 rounding of the result
-// itself (the Abramowitz-Stegun 7.1.26 form used before: 2.1e-7, with a v_rcp_f32 besides the exponential;
-// transcendentals were half of the epilogue's arithmetic).  Four values at a time: the Horner steps are
-// v_pk_fma_f32.
+// accuracy for either sign.  log2 Phi(-a) is smooth and nearly quadratic, so a degree-9 polynomial fitted on
+// [0, 5.5] (Chebyshev nodes) followed by ONE v_exp_f32 reproduces Phi(-a) to 7e-7 relative there, and it
+// extrapolates to a = 9 within 0.5 in the exponent, where a * Phi(-a) = 1e-18 is below every format in use:
+// a is clamped to 9.  |error of the result| <= 2.4e-7 over [-9, 9], which is the f32 rounding of the result
+// itself (the Abramowitz-Stegun 7.1.26 form used before: 2.1e-7, with a v_rcp_f32 besides the exponential).
+// Four values at a time: the Horner steps are v_pk_fma_f32.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
     // v_med3_f32 for the clamps: fminf / fmaxf cost a canonicalising v_max_f32 each on top
-    auto clamp_abs = [](float v) { return __builtin_amdgcn_fmed3f(fabsf(v), 0.0f, 5.5f); };
+    auto clamp_abs = [](float v) { return __builtin_amdgcn_fmed3f(fabsf(v), 0.0f, 9.0f); };
     auto positive = [](float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); };
     const f32x2 a0 = {clamp_abs(x[0]), clamp_abs(x[1])}, a1 = {clamp_abs(x[2]), clamp_abs(x[3])};
     const f32x2 p0 = {positive(x[0]), positive(x[1])}, p1 = {positive(x[2]), positive(x[3])};
