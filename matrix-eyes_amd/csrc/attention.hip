@@ -51,6 +51,22 @@ constexpr int TILE_BYTES = KT * 128;
 
 // NSLOT: LDS ring slots (a K and a V tile each; 2 or 3); MINW: waves per SIMD the register allocation
 // must allow (launched as <2, 4>: 32 KiB of LDS and 128 VGPRs, three of them spilled)
+#ifdef ME_ATT_STAMPS
+// Diagnostic build only (tools/attn_stamps.py): per-wave phase accounting in shader clocks.  Reading the clock
+// waits for all LDS operations in flight (lgkmcnt), so the phases are serialised a little more than in the
+// product kernel.  [0] DMA wait + barrier, [1] staging issue, [2] S = K Q^T and the running max, [3] rescale +
+// exponentials, [4] P V, [5] closing LDS wait, [6] everything (prologue and epilogue included).
+__device__ unsigned long long* g_att_stamps = nullptr;
+#define ATT_PH(i)                                                  \
+    do {                                                           \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        ph[i] += t_now - t_last;                                   \
+        t_last = t_now;                                            \
+    } while (0)
+#else
+#define ATT_PH(i)
+#endif
+
 template <typename T, int NSLOT, int MINW>
 __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int tokens, int heads,
@@ -58,6 +74,11 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
     typedef typename Mfma32<T>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ME_ATT_STAMPS
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_last = t_begin;
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int C = heads * 64;
@@ -80,25 +101,6 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
     const T* qbase = qkv + head * 64;
     const T* kbase = qkv + C + head * 64;
     const T* vbase = qkv + 2 * C + head * 64;
-
-    // Q fragments: B operand, lane holds Q[q0 + r][16 s + 8 h + 0..7]
-    frag qf[4];
-    {
-        int q = q0 + r;
-        q = q < tokens ? q : tokens - 1;
-        const T* qp = qbase + (row0 + q) * ldq + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
-        // settle these loads here: left pending into the loop, the compiler's wait for them sits at the
-        // first MFMA of EVERY tile and, returns being in order, waits for the ring's DMA as well
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            i32x4 t = __builtin_bit_cast(i32x4, qf[s]);
-            asm volatile("" : "+v"(t));
-            qf[s] = __builtin_bit_cast(frag, t);
-        }
-    }
 
     // K/V staging by LDS-DMA: a wave-instruction moves 8 rows x 128 B (lane -> row lane / 8, 16-byte chunk
     // lane % 8); the LDS image is linear in the lane, so the swizzle goes on the SOURCE chunk: the LDS slot
@@ -150,6 +152,27 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
         stage(1);
     }
 
+    // (after the first tile's DMA has been issued: the two memory latencies of a workgroup's start overlap)
+    // Q fragments: B operand, lane holds Q[q0 + r][16 s + 8 h + 0..7]
+    frag qf[4];
+    {
+        int q = q0 + r;
+        q = q < tokens ? q : tokens - 1;
+        const T* qp = qbase + (row0 + q) * ldq + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+        // settle these loads here: left pending into the loop, the compiler's wait for them sits at the
+        // first MFMA of EVERY tile and, returns being in order, waits for the ring's DMA as well
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 t = __builtin_bit_cast(i32x4, qf[s]);
+            asm volatile("" : "+v"(t));
+            qf[s] = __builtin_bit_cast(frag, t);
+        }
+    }
+
+
     // One KV tile.  TAIL (last tile only) masks the keys past the end.  Softmax runs on raw scores:
     // p = exp2(s*c - m*c) with c = scale*log2(e) folded into one FMA; O and l are rescaled only in the
     // tiles where some lane's running max actually grows (exact, and rare after the first tiles).
@@ -162,16 +185,21 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
     int slot = 0, fill = NSLOT - 1;
     auto tile = [&](int kt, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
+#ifdef ME_ATT_STAMPS
+        t_last = __builtin_amdgcn_s_memtime();
+#endif
         if (NSLOT == 3 && kt + 1 < nkt)
             wait_vmcnt<4>();  // the next tile's pieces may stay in flight
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ATT_PH(0);
         if (kt + NSLOT - 1 < nkt) {
             stage_offsets(kt + NSLOT - 1);
             stage(fill);
         }
+        ATT_PH(1);
         const char* kb = smem + slot * (2 * TILE_BYTES);
         const char* vb = kb + TILE_BYTES;
         slot = slot == NSLOT - 1 ? 0 : slot + 1;
@@ -203,6 +231,7 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
                 mloc = fmaxf(mloc, s[ks][g]);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        ATT_PH(2);
         if (__any(mloc > m_run)) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
@@ -225,6 +254,7 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
                 psum += pv;
             }
         l_run += psum;
+        ATT_PH(3);
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -252,9 +282,11 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
                     o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, both), pf, o[d]);
                 }
             }
+        ATT_PH(4);
         }  // active
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the
                                                              // barrier that lets its slot be restaged
+        ATT_PH(5);
     };
     for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type());
     if ((tokens % KT) == 1 && nkt >= 2) {
@@ -313,10 +345,24 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
                 *reinterpret_cast<v4*>(op + d * 32 + 8 * g4) = v;
             }
     }
+#ifdef ME_ATT_STAMPS
+    if (g_att_stamps && lane == 0 && blockIdx.x < 4096) {
+        ph[6] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int i = 0; i < 7; ++i) g_att_stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+        g_att_stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = active ? 1 : 0;
+    }
+#endif
 }
 
 
 }  // namespace
+
+#ifdef ME_ATT_STAMPS
+extern "C" int32_t me_debug_set_att_stamps(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
                       int32_t dtype, hipStream_t stream, const RowSegs* segs_opt) {
