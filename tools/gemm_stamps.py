@@ -9,7 +9,8 @@ ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 lib.me_debug_set_stamps.argtypes = [C.c_void_p]
 M = int(os.environ.get("STAMPS_M", 35 * 577))
-for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", 0), (1024, 1024, "proj-resid", 0), (1024, 4096, "fc2-resid", 0)]:
+PP = int(os.environ.get("STAMPS_PP_CFG", 0))   # 0 = the 8-wave two-group kernel, 5 = the 16-wave one (tile stamps only)
+for (N, K, name, cfg) in [(3072, 1024, "qkv", PP), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", PP), (1024, 1024, "proj-resid", PP), (1024, 4096, "fc2-resid", PP)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     bias = torch.randn(N, device="cuda"); out16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
@@ -27,11 +28,11 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096,
     lib.me_debug_set_stamps(None)
     raw = stamps.cpu().numpy()
     s = raw.reshape(-1, 16).astype(np.float64)
-    nwg = int(np.sum(s[:256, 0] > 0)) if cfg == 0 else int(np.sum(s[:512, 0] > 0))
-    nw = 8 if cfg == 0 else 4
-    npz = 8 if cfg == 0 else 4
+    nwg = int(np.sum(s[:256, 0] > 0)) if cfg in (0, 5) else int(np.sum(s[:512, 0] > 0))
+    nw = 8 if cfg in (0, 5) else 4
+    npz = 8 if cfg in (0, 5) else 4
     ph = raw[nwg * 16: nwg * 16 + nwg * nw * npz].reshape(nwg, nw, npz).astype(np.float64)
-    names = ["dma top", "k-substep 0", "dma mid", "k-substep 1", "vmcnt", "barrier"] if cfg == 0 else ["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]
+    names = ["dma top", "k-substep 0", "dma mid", "k-substep 1", "vmcnt", "barrier"] if cfg in (0, 5) else ["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]
     s = s[:nwg]
     t0 = s[:, 0].min()
     us = (s - t0) / 100.0   # 100 MHz
