@@ -196,6 +196,21 @@ def test_extract_depth_full_size(dtype):
     assert abs(float(fov[0]) - float(ref_fov[0])) < 0.1
 
 
+def test_full_size_batch_equals_loop_of_batch_one():
+    """BASELINE configs[2] gives each GPU several images per step: at the full size (70 + 2 + 2 windows in three
+    row segments, GEMM tiles in other rounds than at batch 1) image i of a batch is bit for bit what a batch of
+    one produces, FOV head included, and a repeated call reproduces itself."""
+    ctx = loaded_ctx("full", "f16")
+    rgb = synthetic_images(2, ctx.cfg.img_size, "structured", seed=77)
+    both, fovs = ctx.extract_depth(rgb, None, want_fov=True)
+    again, fovs2 = ctx.extract_depth(rgb, None, want_fov=True)
+    assert np.array_equal(both, again) and np.array_equal(fovs, fovs2)
+    for i in range(2):
+        one, fov1 = ctx.extract_depth(rgb[i:i + 1], None, want_fov=True)
+        assert np.array_equal(both[i], one[0]) and fovs[i] == fov1[0]
+    assert not np.array_equal(both[0], both[1]) and np.isfinite(both).all()
+
+
 def test_reconstruction_end_to_end_with_pt_checkpoint(tmp_path):
     """reconstruction.rs:155-205 through the host mirror: photo file + PyTorch .pt checkpoint in,
     depth-map PNG / stereogram PNG / OBJ+MTL out"""
