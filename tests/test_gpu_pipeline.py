@@ -192,7 +192,11 @@ def test_extract_depth_full_size(dtype):
     ref, ref_fov = O.extract_depth(img, None, w, oracle_cfg(cfg))
     rep = depth_error_report(got, ref.numpy())
     print("full-size", dtype, rep, float(fov[0]), float(ref_fov[0]))
-    assert rep["rel_l2"] < 2.0e-3
+    # north_star: depth within 1e-3 relative of the CPU reference.  Measured (deterministic): median per-pixel
+    # relative error 2.0e-4, relative L2 over the map 1.01e-3 -- about 23 sequential f16 operand roundings of
+    # 2.1e-4 each in quadrature; the bounds leave a fifth of headroom over those figures
+    assert rep["median"] < 2.5e-4
+    assert rep["rel_l2"] < 1.2e-3
     assert abs(float(fov[0]) - float(ref_fov[0])) < 0.1
 
 
