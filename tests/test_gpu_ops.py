@@ -86,6 +86,43 @@ def test_gelu_function(cfg):
     assert float((out16 != want16).float().mean()) < 1e-3
 
 
+def test_linear_random_shapes():
+    """120 random problems per run of the seed: M from 1 (a single row) to a few tiles and ragged edges, N any
+    multiple of 4, K any multiple of 64, every tile configuration and the automatic choice, plain and residual
+    epilogue.  Catches indexing at tile edges that the model's own shapes never reach."""
+    import random
+    ctx = ctx_for("tiny", "f16")
+    rnd = random.Random(20240)
+    ncfg = ctx.lib.me_op_gemm_config_count()
+    for it in range(120):
+        M = rnd.choice([1, 2, 7, 63, 64, 65, 127, 129, 255, 257, 300, 511, 513, 777, rnd.randrange(1, 1500)])
+        N = 4 * rnd.choice([1, 2, 3, 7, 8, 15, 16, 31, 33, 64, 65, rnd.randrange(1, 160)])
+        K = 64 * rnd.choice([1, 2, 3, 4, 5, 9, 16])
+        cfg = rnd.randrange(-1, ncfg)
+        g = torch.Generator().manual_seed(it)
+        a = dev16(torch.randn(M, K, generator=g), "f16")
+        w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), "f16")
+        bias = torch.randn(N, generator=g).cuda()
+        ref = a.double() @ w.double().T + bias.double()
+        if it % 3 == 2:
+            gamma = torch.rand(N, generator=g).cuda()
+            x32 = torch.randn(M, N, generator=g).cuda()
+            want = ref * gamma.double() + x32.double()
+            torch.cuda.synchronize()       # the context launches on its own stream, torch filled these on its
+            _check(ctx, ctx.lib.me_op_linear_residual(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x32), cfg))
+            got = x32
+        else:
+            got = torch.full((M + 1, N), 7.0, dtype=torch.float32, device="cuda")      # one guard row behind the output
+            torch.cuda.synchronize()
+            _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, N, K, ptr(a), ptr(w), ptr(bias), None, ptr(got), 0, cfg))
+            ctx.synchronize()
+            assert bool((got[M] == 7.0).all()), (it, M, N, K, cfg)
+            got, want = got[:M], ref
+        ctx.synchronize()
+        err = float((got.double() - want).abs().max())
+        assert err < 3e-5 * max(1.0, float(want.abs().max())), (it, M, N, K, cfg, err)
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 3])
 @pytest.mark.parametrize("shape", [(20195, 1024, 256), (9000, 2304, 192), (70000, 256, 128)])
 def test_linear_persistent_rounds(cfg, shape):
