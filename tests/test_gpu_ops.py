@@ -193,6 +193,28 @@ def test_attention(dtype, tokens, windows, heads):
     assert rel_l2(out.float(), ref) < 1.5 * OUT_EPS[dtype]
 
 
+def test_attention_token_counts():
+    """Every way the sequence can end: one token, one short of / exactly / one past a 64-key tile (the single
+    tail key is folded in as a rank-one update) and a 128-query block, the model's 577 and a few in between; a
+    guard row behind the output stays untouched."""
+    ctx = ctx_for("tiny", "f16")
+    for tokens in [1, 2, 31, 63, 64, 65, 66, 127, 128, 129, 191, 192, 193, 256, 257, 300, 576, 577, 578, 640, 641]:
+        windows, heads = (2, 2) if tokens < 400 else (1, 1)
+        C = heads * 64
+        g = torch.Generator().manual_seed(tokens)
+        qkv = dev16(torch.randn(windows * tokens, 3 * C, generator=g) * 1.5, "f16")
+        out = torch.full((windows * tokens + 1, C), 7.0, dtype=torch.float16, device="cuda")
+        torch.cuda.synchronize()
+        _check(ctx, ctx.lib.me_op_attention(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+        ctx.synchronize()
+        x = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        q, k, v = x[0] * 0.125, x[1], x[2]
+        ref = (torch.softmax(q @ k.transpose(3, 2), dim=3) @ v).transpose(1, 2).reshape(windows * tokens, C)
+        assert bool((out[windows * tokens] == 7.0).all()), tokens
+        assert max_err_over_max(out[:-1].float(), ref) < 2 * OUT_EPS["f16"], tokens
+        assert rel_l2(out[:-1].float(), ref) < 1.5 * OUT_EPS["f16"], tokens
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_large_scores(dtype):
     """one key dominates from the middle of the sequence on: exercises the running-max rescale"""
