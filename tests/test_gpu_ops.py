@@ -294,6 +294,49 @@ def test_conv2d(dtype, case, cfg):
     assert float(out16[:, -1].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
 
 
+def test_conv2d_random_shapes():
+    """40 random convolutions: non-square and odd maps, 1x1 and 3x3, stride 1 and 2, any tile configuration, with
+    and without the two f32 residual inputs and the fused ReLU -- against torch.nn.functional.conv2d on the same
+    16-bit operands; the zero border of the 16-bit output stays zero."""
+    import random
+    ctx = ctx_for("tiny", "f16")
+    rnd = random.Random(777)
+    ncfg = ctx.lib.me_op_gemm_config_count()
+    for it in range(40):
+        k = rnd.choice([1, 3, 3])
+        s = rnd.choice([1, 1, 2])
+        B = rnd.choice([1, 1, 2, 3])
+        H, W = (2 * rnd.randrange(1, 14), 2 * rnd.randrange(1, 14)) if s == 2 else (rnd.randrange(1, 27), rnd.randrange(1, 27))
+        Cin, Cout = 64 * rnd.choice([1, 2, 3, 4]), 4 * rnd.choice([1, 2, 8, 9, 16, 33, 64])
+        cfg = rnd.randrange(-1, ncfg)
+        with_res, relu = rnd.random() < 0.5, rnd.random() < 0.5
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        bias = torch.randn(Cout, generator=g)
+        Ho, Wo = H // s, W // s
+        res = torch.randn(B * Ho * Wo, Cout, generator=g).cuda() if with_res else None
+        res2 = torch.randn(B * Ho * Wo, Cout, generator=g).cuda() if with_res else None
+        out32 = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32, device="cuda")
+        out16 = torch.zeros(B, Ho + 2, Wo + 2, Cout, dtype=torch.float16, device="cuda")
+        xb, w16, bias_d = bordered(x, "f16"), dev16(pack_conv(w), "f16"), bias.cuda()
+        torch.cuda.synchronize()
+        _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, k, s, ptr(bias_d),
+                                         ptr(res), ptr(res2), ptr(out32), ptr(out16), 1, 2 if relu else 0, 0, cfg))
+        ctx.synchronize()
+        x16 = xb[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).double().cpu()
+        ref = F.conv2d(x16, dev16(w, "f16").double().cpu(), bias.double(), stride=s, padding=(k - 1) // 2)
+        ref = ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+        if with_res:
+            ref = ref + res.double().cpu() + res2.double().cpu()
+        tag = (it, B, H, W, Cin, Cout, k, s, cfg, with_res, relu)
+        assert max_abs_rel(out32.cpu(), ref) < 3e-5, tag
+        got16 = out16[:, 1:Ho + 1, 1:Wo + 1, :].reshape(B * Ho * Wo, Cout).float().cpu()
+        assert max_abs_rel(got16, F.relu(ref) if relu else ref) < 6 * OUT_EPS["f16"] * 4, tag
+        assert float(out16[:, 0].abs().max()) == 0 and float(out16[:, :, 0].abs().max()) == 0, tag
+        assert float(out16[:, -1].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0, tag
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_conv_transpose(dtype, cfg):
