@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 1
+#define ME_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum {
@@ -51,11 +51,13 @@ enum {
 /* ---- arithmetic type of the MFMA operands (accumulation is always f32) --------------- */
 enum {
     ME_DTYPE_F16 = 0,  /* default: the checkpoint is fp16, so weights are exact          */
-    ME_DTYPE_BF16 = 1
+    ME_DTYPE_BF16 = 1,
+    ME_DTYPE_FP8 = 2   /* BASELINE configs[3]: the ViT linears on MX block-scaled fp8 (e4m3 values, one e8m0
+                          scale per 32 K-elements, v_mfma_scale_f32_16x16x128_f8f6f4); everything else f16 */
 };
 
 /* ---- element type of a weight tensor handed to me_load_weight ------------------------ */
-enum { ME_WEIGHT_F32 = 0, ME_WEIGHT_F16 = 1 };
+enum { ME_WEIGHT_F32 = 0, ME_WEIGHT_F16 = 1, ME_WEIGHT_BF16 = 2, ME_WEIGHT_F64 = 3 };
 
 /* ---- which DINOv2 ViT-L of the three in the model (encoder.rs:23-24, fov.rs:25) ------- */
 enum { ME_VIT_PATCH_ENCODER = 0, ME_VIT_IMAGE_ENCODER = 1, ME_VIT_FOV_ENCODER = 2 };
@@ -86,6 +88,13 @@ typedef struct me_model_config {
     float ln_eps;          /* Burn LayerNormConfig default 1e-5 (vit.rs:141) */
     int32_t align_corners; /* bilinear pyramid (encoder.rs:128-137): 1 = Burn's historical
                               align_corners=true, 0 = half-pixel centres                  */
+    int32_t split_operands; /* bit mask of the stages whose 16-bit activation operands are carried as hi + lo
+                               pairs against duplicated weights (2x the MFMA work of that stage, operand
+                               rounding 2^-22 instead of 2^-11): 1 = encoder upsample / fuse convs
+                               (encoder.rs:307-325), 2 = fusion deconv + out_conv (decoder.rs:95-101), 4 = head
+                               (mod.rs:323-333), 8 = decoder.convs (decoder.rs:189-195).  me_default_config: 3
+                               (full-size depth error 7e-4 relative L2 against the fp32 reference; 0: 1.0e-3,
+                               7: 5.8e-4, 15: 5.2e-4 -- DESIGN.md section 5) */
 } me_model_config;
 
 typedef struct me_ctx me_ctx;
@@ -122,6 +131,17 @@ int32_t me_expected_weight(const me_ctx* ctx, int32_t index, const char** name, 
                            int32_t* ndim);
 /* Fails with ME_ERR_MISSING_WEIGHT while any expected tensor is absent (mod.rs:241-243). */
 int32_t me_weights_finalize(me_ctx* ctx);
+/* mod.rs:229-249 load_record for a caller without a PyTorch-checkpoint reader of its own: maps the
+   `torch.save` zip archive at `path` (the reference reads it through burn-store's PytorchStore, mod.rs:231),
+   loads every tensor the model expects (f16 / f32 / bf16 / f64 storage) and finalizes.  Keys the model does
+   not use are skipped, as in the reference, where each part is applied from the full snapshot list and only
+   `result.errors` / `result.missing` are checked (mod.rs:236-243); they are listed by
+   me_unused_weight_count / me_unused_weight_name.  An unreadable or malformed file is ME_ERR_IO
+   (LoaderError::Pytorch), a tensor of the wrong shape ME_ERR_BAD_WEIGHT, an absent one
+   ME_ERR_MISSING_WEIGHT. */
+int32_t me_load_checkpoint_pt(me_ctx* ctx, const char* path);
+int32_t me_unused_weight_count(const me_ctx* ctx);
+const char* me_unused_weight_name(const me_ctx* ctx, int32_t index);
 /* Size of the packed device weight arena, bytes. */
 int64_t me_weight_arena_bytes(const me_ctx* ctx);
 /* Device address of the arena, for a caller that moves the packed weights with its own collective
@@ -186,6 +206,11 @@ int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, cons
 int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* min_out,
                               float* max_out);
 
+/* The same without the host round trip: depth and minmax_dev are DEVICE memory, the range {min, max} stays in
+   minmax_dev[0..1] for me_stereogram_dev_range / me_depthmap_rgb_dev_range queued behind it on the context's
+   stream (DepthMap::new -> output_image chained on the GPU, output.rs:44-75 + :100-121). */
+int32_t me_depth_clamp_minmax_async(me_ctx* ctx, float* depth, int64_t count, float* minmax_dev);
+
 /* output.rs:141-193 output_stereogram.  depth [rows,cols] already clamped (DepthMap.data);
    noise [out_h,out_w,3] is the reference's per-row rand stream made an input;
    out [out_h,out_w,3].  Bit-exact with the reference's f32 arithmetic. */
@@ -193,10 +218,19 @@ int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t col
                       float max_depth, int32_t out_w, int32_t out_h, float amplitude,
                       const uint8_t* noise, uint8_t* out);
 
+/* me_stereogram with the depth range read from device memory (me_depth_clamp_minmax_async). */
+int32_t me_stereogram_dev_range(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols,
+                                const float* minmax_dev, int32_t out_w, int32_t out_h, float amplitude,
+                                const uint8_t* noise, uint8_t* out);
+
 /* output.rs:123-131 + 633-714 map_depth: depth [count] -> rgb [count,3] (before the Lanczos
    resize, which is the identity at the native size). */
 int32_t me_depthmap_rgb(me_ctx* ctx, const float* depth, int64_t count, float min_depth,
                         float max_depth, uint8_t* rgb);
+
+/* me_depthmap_rgb with the depth range read from device memory (me_depth_clamp_minmax_async). */
+int32_t me_depthmap_rgb_dev_range(me_ctx* ctx, const float* depth, int64_t count, const float* minmax_dev,
+                                  uint8_t* rgb);
 
 /* output.rs:264-363 IndexedMesh::new + for_each_face + remap_face.
    depth [height,width] (DepthMap.data, stride `width`).  vertex_index [height*width]: the

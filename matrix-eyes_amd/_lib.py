@@ -9,8 +9,8 @@ ERROR_NAMES = {
     1: "BAD_ARG", 2: "BAD_SHAPE", 3: "MISSING_WEIGHT", 4: "BAD_WEIGHT", 5: "HIP", 6: "RCCL",
     7: "IO", 8: "NOT_READY", 9: "OOM",
 }
-ME_DTYPE_F16, ME_DTYPE_BF16 = 0, 1
-ME_WEIGHT_F32, ME_WEIGHT_F16 = 0, 1
+ME_DTYPE_F16, ME_DTYPE_BF16, ME_DTYPE_FP8 = 0, 1, 2
+ME_WEIGHT_F32, ME_WEIGHT_F16, ME_WEIGHT_BF16, ME_WEIGHT_F64 = 0, 1, 2, 3
 ME_VIT_PATCH_ENCODER, ME_VIT_IMAGE_ENCODER, ME_VIT_FOV_ENCODER = 0, 1, 2
 
 
@@ -26,7 +26,7 @@ class CModelConfig(C.Structure):
         ("grid", C.c_int32), ("embed_dim", C.c_int32), ("num_heads", C.c_int32),
         ("depth", C.c_int32), ("tap_blocks", C.c_int32 * 2), ("enc_dims", C.c_int32 * 4),
         ("dec_dim", C.c_int32), ("head_dims", C.c_int32 * 2), ("ln_eps", C.c_float),
-        ("align_corners", C.c_int32),
+        ("align_corners", C.c_int32), ("split_operands", C.c_int32),
     ]
 
 
@@ -48,6 +48,9 @@ SIGNATURES = {
     "me_expected_weight_count": (_i32, [_vp]),
     "me_expected_weight": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i32)]),
     "me_weights_finalize": (_i32, [_vp]),
+    "me_load_checkpoint_pt": (_i32, [_vp, C.c_char_p]),
+    "me_unused_weight_count": (_i32, [_vp]),
+    "me_unused_weight_name": (C.c_char_p, [_vp, _i32]),
     "me_weight_arena_bytes": (_i64, [_vp]),
     "me_weight_arena_ptr": (_vp, [_vp]),
     "me_weights_adopt": (_i32, [_vp]),
@@ -62,7 +65,10 @@ SIGNATURES = {
     "me_extract_depth": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "me_extract_depth_u8": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "me_depth_clamp_minmax": (_i32, [_vp, _vp, _i64, C.POINTER(_f32), C.POINTER(_f32)]),
+    "me_depth_clamp_minmax_async": (_i32, [_vp, _vp, _i64, _vp]),
     "me_stereogram": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp]),
+    "me_stereogram_dev_range": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp]),
+    "me_depthmap_rgb_dev_range": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "me_depthmap_rgb": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "me_mesh_index": (_i32, [_vp, _vp, _i32, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "me_mesh_vertices": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _u32, _u32, _vp, _vp]),

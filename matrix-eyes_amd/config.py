@@ -19,6 +19,7 @@ class ModelConfig:
     head_dims: Tuple[int, int] = (32, 1)  # mod.rs:310
     ln_eps: float = 1e-5                # Burn LayerNormConfig default
     align_corners: bool = True          # Burn bilinear
+    split_operands: int = 3             # me_model_config.split_operands: hi + lo operand stages (bit mask)
 
     @property
     def window(self) -> int:
@@ -42,6 +43,7 @@ class ModelConfig:
         c.head_dims[0], c.head_dims[1] = self.head_dims
         c.ln_eps = self.ln_eps
         c.align_corners = 1 if self.align_corners else 0
+        c.split_operands = self.split_operands
         return c
 
     @staticmethod

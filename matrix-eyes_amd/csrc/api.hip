@@ -2,6 +2,7 @@
 // Every entry point converts internal me::Error into a status code + last_error text; nothing
 // throws or aborts across the boundary.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 
@@ -70,6 +71,8 @@ void validate_config(const me_model_config& c) {
              ME_ERR_BAD_SHAPE, "head_dims {%d,%d}: need {<=32 multiple of 4, 1}", c.head_dims[0],
              c.head_dims[1]);
     ME_CHECK(c.ln_eps > 0.f, ME_ERR_BAD_ARG, "ln_eps %g", (double)c.ln_eps);
+    ME_CHECK(c.split_operands >= 0 && c.split_operands <= 15, ME_ERR_BAD_ARG, "split_operands %d not in [0, 15]",
+             c.split_operands);
 }
 
 }  // namespace
@@ -105,6 +108,7 @@ int32_t me_default_config(me_model_config* cfg) {
     cfg->head_dims[0] = 32, cfg->head_dims[1] = 1;
     cfg->ln_eps = 1e-5f;
     cfg->align_corners = 1;
+    cfg->split_operands = 3;
     return ME_OK;
 }
 
@@ -129,15 +133,13 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
             ctx->cfg = *cfg;
         else
             me_default_config(&ctx->cfg);
+        // diagnostic override of me_model_config.split_operands (tools/split_budget.py)
+        if (const char* e = getenv("ME_SPLIT_OPERANDS")) ctx->cfg.split_operands = atoi(e);
         validate_config(ctx->cfg);
+        ctx->split_mask = ctx->cfg.split_operands;  // model.h SplitStage bits
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
-        for (int i = 0; i < 2; ++i)
-            ME_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-        ME_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        ME_HIP(hipEventCreateWithFlags(&ctx->ev_img, hipEventDisableTiming));
-        ME_HIP(hipEventCreateWithFlags(&ctx->ev_fov, hipEventDisableTiming));
         build_weight_table(ctx);
         ME_HIP(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
         resolve_weights(ctx);
@@ -158,13 +160,6 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    for (int i = 0; i < 2; ++i)
-        if (ctx->side[i]) {
-            (void)hipStreamSynchronize(ctx->side[i]);
-            (void)hipStreamDestroy(ctx->side[i]);
-        }
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_img, ctx->ev_fov})
-        if (e) (void)hipEventDestroy(e);
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -220,6 +215,19 @@ int32_t me_weights_finalize(me_ctx* ctx) {
     ME_API_BEGIN(ctx)
     finalize_weights(ctx);
     ME_API_END(ctx)
+}
+
+int32_t me_load_checkpoint_pt(me_ctx* ctx, const char* path) {
+    ME_API_BEGIN(ctx)
+    load_checkpoint_pt(ctx, path);
+    ME_API_END(ctx)
+}
+
+int32_t me_unused_weight_count(const me_ctx* ctx) { return ctx ? (int32_t)ctx->unused_weights.size() : 0; }
+
+const char* me_unused_weight_name(const me_ctx* ctx, int32_t index) {
+    if (!ctx || index < 0 || index >= (int32_t)ctx->unused_weights.size()) return nullptr;
+    return ctx->unused_weights[index].c_str();
 }
 
 int64_t me_weight_arena_bytes(const me_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
@@ -327,7 +335,7 @@ int32_t me_encoder_forward_encodings(me_ctx* ctx, const float* x, int32_t batch,
                                     H[i], Cc[i], ctx->stream);
         else
             nhwc16_to_nchw32_launch(ctx->bufs.at(names[i]).p, (float*)o.dev, batch, H[i], H[i], Cc[i],
-                                    1, ctx->dtype, ctx->stream);
+                                    1, ctx->dtype, ctx->stream, ctx->split(SPLIT_DEC_CONVS));
         finish(ctx, o);
     }
     ME_API_END(ctx)
@@ -350,10 +358,11 @@ int32_t me_decoder_forward(me_ctx* ctx, const float* const encodings[5], int32_t
         const size_t n = (size_t)batch * Cc[i] * H[i] * H[i];
         const float* src =
             (const float*)to_device(ctx, encodings[i], n * 4, "api.dec.in" + std::to_string(i));
-        void* d16 = site_buf(ctx, names[i], (size_t)batch * (H[i] + 2) * (H[i] + 2) * Cc[i] * 2);
+        const bool sp = i > 0 && ctx->split(SPLIT_DEC_CONVS);  // encoding 0 only feeds the residual units
+        void* d16 = site_buf(ctx, names[i], (size_t)batch * (H[i] + 2) * (H[i] + 2) * Cc[i] * 2 * (sp ? 2 : 1));
         float* d32 = i == 0 ? (float*)site_buf(ctx, "enc0.f32", n * 4) : nullptr;
         nchw32_to_nhwc_launch(src, d32, d16, batch, H[i], H[i], Cc[i], 1, i == 0 ? 1 : 0, ctx->dtype,
-                              ctx->stream);
+                              ctx->stream, sp);
     }
     stage_decoder(ctx, batch, true);
     OutBuf of = out_buf(ctx, features, (size_t)batch * dec * H[0] * H[0] * 4, "api.dec.feat");
@@ -376,8 +385,9 @@ int32_t me_head_forward(me_ctx* ctx, const float* features, int32_t batch,
     const int S = ctx->S(), Hh = S / 2, dec = ctx->cfg.dec_dim;
     const size_t n = (size_t)batch * dec * Hh * Hh;
     const float* src = (const float*)to_device(ctx, features, n * 4, "api.head.in");
-    void* f16b = site_buf(ctx, "features.16b", (size_t)batch * (Hh + 2) * (Hh + 2) * dec * 2);
-    nchw32_to_nhwc_launch(src, nullptr, f16b, batch, Hh, Hh, dec, 1, 0, ctx->dtype, ctx->stream);
+    const bool sp = ctx->split(SPLIT_HEAD);
+    void* f16b = site_buf(ctx, "features.16b", (size_t)batch * (Hh + 2) * (Hh + 2) * dec * 2 * (sp ? 2 : 1));
+    nchw32_to_nhwc_launch(src, nullptr, f16b, batch, Hh, Hh, dec, 1, 0, ctx->dtype, ctx->stream, sp);
     OutBuf o = out_buf(ctx, canonical_inverse_depth, (size_t)batch * S * S * 4, "io.depth");
     stage_head(ctx, batch, nullptr, false, (float*)o.dev);
     finish(ctx, o);
@@ -400,7 +410,7 @@ int32_t me_fov_forward(me_ctx* ctx, const float* x, const float* lowres_feature,
     nchw32_to_nhwc_launch(low, low32, nullptr, batch, 2 * g, 2 * g, dec, 0, 0, ctx->dtype, ctx->stream);
     OutBuf o = out_buf(ctx, fov_deg, (size_t)batch * 4, "fov_deg");
     stage_fov_vit(ctx, batch, ctx->stream);
-    stage_fov_tail(ctx, batch, (float*)o.dev, false);
+    stage_fov_tail(ctx, batch, (float*)o.dev);
     finish(ctx, o);
     ME_API_END(ctx)
 }
@@ -445,7 +455,7 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
         // mod.rs:343-358
         ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
         ProgressRange r(ctx, dec_end, head_lo);
-        stage_fov_tail(ctx, batch, (float*)ofov.dev, true);
+        stage_fov_tail(ctx, batch, (float*)ofov.dev);
     }
     OutBuf o = out_buf(ctx, inverse_depth, (size_t)batch * S * S * 4, "io.depth");
     {
@@ -504,10 +514,19 @@ int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* m
     ME_API_END(ctx)
 }
 
-int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols, float min_depth,
-                      float max_depth, int32_t out_w, int32_t out_h, float amplitude,
-                      const uint8_t* noise, uint8_t* out) {
+int32_t me_depth_clamp_minmax_async(me_ctx* ctx, float* depth, int64_t count, float* minmax_dev) {
     ME_API_BEGIN(ctx)
+    ME_CHECK(depth && minmax_dev && count > 0, ME_ERR_BAD_ARG, "me_depth_clamp_minmax_async: bad argument");
+    ME_CHECK(is_device_ptr(depth) && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG,
+             "me_depth_clamp_minmax_async: depth and minmax_dev must be device memory");
+    depth_clamp_minmax_launch(depth, count, minmax_dev, ctx->stream);
+    ME_API_END(ctx)
+}
+
+namespace {
+void stereogram_impl(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols, float min_depth, float max_depth,
+                     const float* range_dev, int32_t out_w, int32_t out_h, float amplitude, const uint8_t* noise,
+                     uint8_t* out) {
     ME_CHECK(depth && noise && out, ME_ERR_BAD_ARG, "me_stereogram: null pointer");
     ME_CHECK(rows > 0 && cols > 0 && out_w > 0 && out_h > 0, ME_ERR_BAD_SHAPE,
              "me_stereogram: %dx%d -> %dx%d", rows, cols, out_w, out_h);
@@ -515,20 +534,49 @@ int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t col
     const float* d = (const float*)to_device(ctx, depth, (size_t)rows * cols * 4, "out.depth");
     const uint8_t* nz = (const uint8_t*)to_device(ctx, noise, nout, "out.noise");
     OutBuf o = out_buf(ctx, out, nout, "out.stereo");
-    stereogram_launch(d, rows, cols, min_depth, max_depth, out_w, out_h, amplitude, nz,
+    stereogram_launch(d, rows, cols, min_depth, max_depth, range_dev, out_w, out_h, amplitude, nz,
                       (uint8_t*)o.dev, ctx->stream);
     finish(ctx, o);
+}
+void depthmap_rgb_impl(me_ctx* ctx, const float* depth, int64_t count, float min_depth, float max_depth,
+                       const float* range_dev, uint8_t* rgb) {
+    ME_CHECK(depth && rgb && count > 0, ME_ERR_BAD_ARG, "me_depthmap_rgb: bad argument");
+    const float* d = (const float*)to_device(ctx, depth, (size_t)count * 4, "out.depth");
+    OutBuf o = out_buf(ctx, rgb, (size_t)count * 3, "out.rgb");
+    depthmap_rgb_launch(d, count, min_depth, max_depth, range_dev, (uint8_t*)o.dev, ctx->stream);
+    finish(ctx, o);
+}
+}  // namespace
+
+int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols, float min_depth,
+                      float max_depth, int32_t out_w, int32_t out_h, float amplitude,
+                      const uint8_t* noise, uint8_t* out) {
+    ME_API_BEGIN(ctx)
+    stereogram_impl(ctx, depth, rows, cols, min_depth, max_depth, nullptr, out_w, out_h, amplitude, noise, out);
+    ME_API_END(ctx)
+}
+
+int32_t me_stereogram_dev_range(me_ctx* ctx, const float* depth, int32_t rows, int32_t cols,
+                                const float* minmax_dev, int32_t out_w, int32_t out_h, float amplitude,
+                                const uint8_t* noise, uint8_t* out) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(minmax_dev && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG, "me_stereogram_dev_range: minmax_dev");
+    stereogram_impl(ctx, depth, rows, cols, 0.f, 0.f, minmax_dev, out_w, out_h, amplitude, noise, out);
     ME_API_END(ctx)
 }
 
 int32_t me_depthmap_rgb(me_ctx* ctx, const float* depth, int64_t count, float min_depth,
                         float max_depth, uint8_t* rgb) {
     ME_API_BEGIN(ctx)
-    ME_CHECK(depth && rgb && count > 0, ME_ERR_BAD_ARG, "me_depthmap_rgb: bad argument");
-    const float* d = (const float*)to_device(ctx, depth, (size_t)count * 4, "out.depth");
-    OutBuf o = out_buf(ctx, rgb, (size_t)count * 3, "out.rgb");
-    depthmap_rgb_launch(d, count, min_depth, max_depth, (uint8_t*)o.dev, ctx->stream);
-    finish(ctx, o);
+    depthmap_rgb_impl(ctx, depth, count, min_depth, max_depth, nullptr, rgb);
+    ME_API_END(ctx)
+}
+
+int32_t me_depthmap_rgb_dev_range(me_ctx* ctx, const float* depth, int64_t count, const float* minmax_dev,
+                                  uint8_t* rgb) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(minmax_dev && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG, "me_depthmap_rgb_dev_range: minmax_dev");
+    depthmap_rgb_impl(ctx, depth, count, 0.f, 0.f, minmax_dev, rgb);
     ME_API_END(ctx)
 }
 

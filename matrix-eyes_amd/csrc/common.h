@@ -149,6 +149,11 @@ struct GemmParams {
     float* out32;          // optional f32 output
     void* out16;           // optional f16/bf16 output
     int64_t ldc;           // row stride (elements) of out32/out16/res32 for row-major outputs
+    int64_t ldc16;         // row / pixel stride of out16 when it differs from ldc (0: same)
+    // Split 16-bit output (pipeline.hip "split operands"): besides hi = T(v) at its place, lo = T(v - hi) is
+    // stored lo_off16 elements further on, so that a consumer whose K axis reads [hi | lo] against
+    // duplicated weights sees v to ~2^-22 instead of 2^-11.  0: plain 16-bit output.
+    int32_t lo_off16;
     int32_t act;           // activation applied to the f16 output (and f32 for EPI_STORE)
     int32_t act16_only;    // 1: activation only on the out16 copy (out32 stays raw)
     int32_t out16_border;  // EPI_STORE/EPI_CONVT: out16 is zero-bordered [B][out_H+2][out_W+2][C]
@@ -226,18 +231,19 @@ void cls_rows_launch(float* tokens, const float* cls, const float* pos, int32_t 
 // encoder.rs:158-208 reshape_feature + merge: token rows of `steps*steps` windows (first window
 // index win0 of each image's 35) -> NHWC f16 map [B][side][side][C], side = merged size.
 // src is f32 tokens (src32) or f16 tokens (src16) with rows (b*35+win)*(P+1) + 1 + patch.
+// split: dst16 holds [hi | lo] pairs of 2*dim channels per pixel (f32 source only)
 void merge_launch(const float* src32, const void* src16, void* dst16, int32_t batch,
                   int32_t windows_per_image, int32_t win0, int32_t steps, int32_t padding,
-                  int32_t grid, int32_t dim, int32_t dtype, hipStream_t stream);
+                  int32_t grid, int32_t dim, int32_t dtype, hipStream_t stream, int32_t split = 0);
 // NHWC (f16 or f32, optional zero border) <-> NCHW f32
 void nhwc16_to_nchw32_launch(const void* src16, float* dst, int32_t batch, int32_t H, int32_t W,
-                             int32_t C, int32_t border, int32_t dtype, hipStream_t stream);
+                             int32_t C, int32_t border, int32_t dtype, hipStream_t stream, int32_t split = 0);
 void nhwc32_to_nchw32_launch(const float* src, float* dst, int32_t batch, int32_t H, int32_t W,
                              int32_t C, hipStream_t stream);
 // NCHW f32 -> NHWC: optional f32 copy, optional f16 copy (zero border, optional relu)
 void nchw32_to_nhwc_launch(const float* src, float* dst32, void* dst16, int32_t batch, int32_t H,
                            int32_t W, int32_t C, int32_t border, int32_t relu16, int32_t dtype,
-                           hipStream_t stream);
+                           hipStream_t stream, int32_t split = 0);
 // NHWC f32 -> 16-bit NHWC with a zero border (optional relu)
 void nhwc32_to_16b_launch(const float* src, void* dst16b, int32_t batch, int32_t H, int32_t W,
                           int32_t C, int32_t relu, int32_t dtype, hipStream_t stream);
@@ -258,11 +264,12 @@ void fov_final_launch(const void* x16 /*NHWC [B][k][k][C]*/, const float* w /*[k
 // ---------------------------------------------------------------------------------------
 void depth_clamp_minmax_launch(float* depth, int64_t count, float* minmax_dev /*[2]*/,
                                hipStream_t stream);
+// range_dev: device {min, max} (from depth_clamp_minmax_launch) used instead of the scalars when not null
 void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min_depth,
-                       float max_depth, int32_t out_w, int32_t out_h, float amplitude,
+                       float max_depth, const float* range_dev, int32_t out_w, int32_t out_h, float amplitude,
                        const uint8_t* noise, uint8_t* out, hipStream_t stream);
 void depthmap_rgb_launch(const float* depth, int64_t count, float min_depth, float max_depth,
-                         uint8_t* rgb, hipStream_t stream);
+                         const float* range_dev, uint8_t* rgb, hipStream_t stream);
 // synchronises the stream (the counts come back to the host)
 void mesh_index_run(const float* depth_dev, int32_t width, int32_t height, int32_t* vertex_index_dev,
                     int32_t* faces_dev /*nullable*/, int64_t* nverts, int64_t* nfaces,

@@ -256,10 +256,12 @@ __global__ void cls_rows_kernel(float* __restrict__ tokens, const float* __restr
 // encoder.rs:191-208 reshape_feature + encoder.rs:158-189 merge, as one row gather:
 // dst[b][Y][X][:] = tokens[(b*wpi + win0 + j*steps + i)*(P+1) + 1 + ty*g + tx][:]
 // ---------------------------------------------------------------------------------------
+// split != 0 (f32 source only): the destination has 2*dim channels per pixel, hi = T(v) in [0, dim) and
+// lo = T(v - hi) in [dim, 2*dim) (split operands, pipeline.hip)
 template <typename T>
 __global__ void merge_kernel(const float* __restrict__ src32, const T* __restrict__ src16,
                              T* __restrict__ dst, int batch, int wpi, int win0, int steps,
-                             int padding, int grid, int dim) {
+                             int padding, int grid, int dim, int split) {
     const int side = steps == 1 ? grid : 2 * (grid - padding) + (steps - 2) * (grid - 2 * padding);
     const int chunks = dim / 8;
     const int64_t total = (int64_t)batch * side * side * chunks;
@@ -293,7 +295,20 @@ __global__ void merge_kernel(const float* __restrict__ src32, const T* __restric
             typename Vec16<T>::v8 o;
             o[0] = (T)a.x, o[1] = (T)a.y, o[2] = (T)a.z, o[3] = (T)a.w;
             o[4] = (T)c.x, o[5] = (T)c.y, o[6] = (T)c.z, o[7] = (T)c.w;
-            reinterpret_cast<typename Vec16<T>::v8*>(dst)[i] = o;
+            if (split) {
+                const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+                typename Vec16<T>::v8 l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float h = (float)o[e];
+                    l[e] = (T)(fabsf(h) == INFINITY ? 0.f : v[e] - h);
+                }
+                const int64_t pix = i / chunks;
+                reinterpret_cast<typename Vec16<T>::v8*>(dst)[pix * 2 * chunks + ch] = o;
+                reinterpret_cast<typename Vec16<T>::v8*>(dst)[pix * 2 * chunks + chunks + ch] = l;
+            } else {
+                reinterpret_cast<typename Vec16<T>::v8*>(dst)[i] = o;
+            }
         } else {
             reinterpret_cast<uint4*>(dst)[i] =
                 *reinterpret_cast<const uint4*>(src16 + srow * dim + ch * 8);
@@ -305,10 +320,11 @@ __global__ void merge_kernel(const float* __restrict__ src32, const T* __restric
 // Layout changes for the module-level entry points (NCHW f32 at the ABI, NHWC inside).
 // 32x32 LDS transposes of the [pixels][channels] matrix.
 // ---------------------------------------------------------------------------------------
+// split != 0 (16-bit source): pixels hold 2*C channels, value = hi[c] + lo[C + c]
 template <typename T, bool SRC32>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src,
                                                            float* __restrict__ dst, int H, int W,
-                                                           int C, int border) {
+                                                           int C, int border, int split) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -326,7 +342,12 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
             } else {
                 pix = (int64_t)b * HW + p;
             }
-            v = SRC32 ? ((const float*)src)[pix * C + c] : (float)((const T*)src)[pix * C + c];
+            if (SRC32)
+                v = ((const float*)src)[pix * C + c];
+            else if (split)
+                v = (float)((const T*)src)[pix * 2 * C + c] + (float)((const T*)src)[pix * 2 * C + C + c];
+            else
+                v = (float)((const T*)src)[pix * C + c];
         }
         tile[ty + 8 * k][tx] = v;
     }
@@ -342,7 +363,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
                                                            float* __restrict__ dst32,
                                                            T* __restrict__ dst16, int H, int W, int C,
-                                                           int border, int relu16) {
+                                                           int border, int relu16, int split) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -368,7 +389,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
                 } else {
                     pix = (int64_t)b * HW + p;
                 }
-                dst16[pix * C + c] = (T)(relu16 ? fmaxf(v, 0.f) : v);
+                const float a = relu16 ? fmaxf(v, 0.f) : v;
+                if (split) {
+                    const T h = (T)a;
+                    dst16[pix * 2 * C + c] = h;
+                    dst16[pix * 2 * C + C + c] = (T)(fabsf((float)h) == INFINITY ? 0.f : a - (float)h);
+                } else {
+                    dst16[pix * C + c] = (T)a;
+                }
             }
         }
     }
@@ -548,47 +576,48 @@ void cls_rows_launch(float* tokens, const float* cls, const float* pos, int32_t 
 
 void merge_launch(const float* src32, const void* src16, void* dst16, int32_t batch,
                   int32_t windows_per_image, int32_t win0, int32_t steps, int32_t padding,
-                  int32_t grid, int32_t dim, int32_t dtype, hipStream_t stream) {
+                  int32_t grid, int32_t dim, int32_t dtype, hipStream_t stream, int32_t split) {
     ME_CHECK(dim % 8 == 0, ME_ERR_BAD_SHAPE, "merge: dim %d", dim);
     ME_CHECK((src32 != nullptr) != (src16 != nullptr), ME_ERR_BAD_ARG, "merge: one source");
+    ME_CHECK(!split || src32, ME_ERR_BAD_ARG, "merge: a split output needs the f32 source");
     const int side = steps == 1 ? grid : 2 * (grid - padding) + (steps - 2) * (grid - 2 * padding);
     const int64_t total = (int64_t)batch * side * side * (dim / 8);
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(merge_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream,
                                    src32, (const f16*)src16, (f16*)dst16, batch, windows_per_image,
-                                   win0, steps, padding, grid, dim),
+                                   win0, steps, padding, grid, dim, split),
                 hipLaunchKernelGGL(merge_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream,
                                    src32, (const bf16*)src16, (bf16*)dst16, batch,
-                                   windows_per_image, win0, steps, padding, grid, dim));
+                                   windows_per_image, win0, steps, padding, grid, dim, split));
 }
 
 void nhwc16_to_nchw32_launch(const void* src16, float* dst, int32_t batch, int32_t H, int32_t W,
-                             int32_t C, int32_t border, int32_t dtype, hipStream_t stream) {
+                             int32_t C, int32_t border, int32_t dtype, hipStream_t stream, int32_t split) {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, 32), (unsigned)cdiv(C, 32), batch);
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16, false>), grid, dim3(256), 0, stream,
-                                   src16, dst, H, W, C, border),
+                                   src16, dst, H, W, C, border, split),
                 hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16, false>), grid, dim3(256), 0, stream,
-                                   src16, dst, H, W, C, border));
+                                   src16, dst, H, W, C, border, split));
 }
 
 void nhwc32_to_nchw32_launch(const float* src, float* dst, int32_t batch, int32_t H, int32_t W,
                              int32_t C, hipStream_t stream) {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, 32), (unsigned)cdiv(C, 32), batch);
     hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16, true>), grid, dim3(256), 0, stream,
-                       (const void*)src, dst, H, W, C, 0);
+                       (const void*)src, dst, H, W, C, 0, 0);
     ME_HIP(hipGetLastError());
 }
 
 void nchw32_to_nhwc_launch(const float* src, float* dst32, void* dst16, int32_t batch, int32_t H,
                            int32_t W, int32_t C, int32_t border, int32_t relu16, int32_t dtype,
-                           hipStream_t stream) {
+                           hipStream_t stream, int32_t split) {
     const dim3 grid((unsigned)cdiv((int64_t)H * W, 32), (unsigned)cdiv(C, 32), batch);
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, dim3(256), 0, stream, src, dst32,
-                                   (f16*)dst16, H, W, C, border, relu16),
+                                   (f16*)dst16, H, W, C, border, relu16, split),
                 hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, grid, dim3(256), 0, stream, src,
-                                   dst32, (bf16*)dst16, H, W, C, border, relu16));
+                                   dst32, (bf16*)dst16, H, W, C, border, relu16, split));
 }
 
 void nhwc32_to_16b_launch(const float* src, void* dst16b, int32_t batch, int32_t H, int32_t W,

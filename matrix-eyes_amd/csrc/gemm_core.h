@@ -237,6 +237,18 @@ __device__ __forceinline__ void store_16bit(T* dst, const float (&a)[8], bool hi
     }
 }
 
+// lo part of a split 16-bit output: T(v - T(v)), the operand rounding error of the hi part made an operand
+template <typename T>
+__device__ __forceinline__ void store_16bit_lo(T* dst, const float (&a)[8], bool hi_ok) {
+    float l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float h = (float)(T)a[e];
+        l[e] = fabsf(h) == INFINITY ? 0.f : a[e] - h;  // an overflowed hi part stays +-inf, as without the split
+    }
+    store_16bit<T>(dst, l, hi_ok);
+}
+
 // v: accumulators of columns n + 4*h .. n + 4*h + 3 (h = 0, 1); hi_ok: the second half exists (n + 4 < N)
 // MODE: 0 = every option checked at run time; 1 / 2 = the ViT fast paths of EPI_STORE (16-bit output
 // only, bias, no residual, no border; 1: no activation (qkv), 2: GELU (fc1)) with the branches gone
@@ -286,11 +298,13 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             a[4 * h] = a0, a[4 * h + 1] = a1, a[4 * h + 2] = a2, a[4 * h + 3] = a3;
         }
         if (p.out16) {
+            const int64_t ld16 = p.ldc16 ? p.ldc16 : p.ldc;
             const int64_t row16 =
                 p.out16_border
-                    ? (((int64_t)r.b * (p.out_H + 2) + r.y + 1) * (p.out_W + 2) + r.x + 1) * p.ldc
-                    : row32;
+                    ? (((int64_t)r.b * (p.out_H + 2) + r.y + 1) * (p.out_W + 2) + r.x + 1) * ld16
+                    : (int64_t)m * ld16;
             store_16bit<T>((T*)p.out16 + row16 + n, a, hi_ok);
+            if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + row16 + n + p.lo_off16, a, hi_ok);
         }
     } else if constexpr (EPI == EPI_RESID_SCALE) {
         const int64_t row32 = (int64_t)m * p.ldc;
@@ -335,11 +349,13 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             a[4 * h + 2] = relu ? fmaxf(x2, 0.f) : x2, a[4 * h + 3] = relu ? fmaxf(x3, 0.f) : x3;
         }
         if (p.out16) {
+            const int64_t ld16 = p.ldc16 ? p.ldc16 : p.ldc;
             const int64_t o =
                 p.out16_border
-                    ? ((((int64_t)r.b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) * p.ldc + lc.co)
-                    : ((((int64_t)r.b * oH + oy) * oW + ox) * p.ldc + lc.co);
+                    ? ((((int64_t)r.b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) * ld16 + lc.co)
+                    : ((((int64_t)r.b * oH + oy) * oW + ox) * ld16 + lc.co);
             store_16bit<T>((T*)p.out16 + o, a, hi_ok);
+            if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + o + p.lo_off16, a, hi_ok);
         }
     }
 }
@@ -484,7 +500,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                            "+v"(lc.gamma[1].x), "+v"(lc.gamma[1].y), "+v"(lc.gamma[1].z), "+v"(lc.gamma[1].w));
         }
         if constexpr (EPI == EPI_STORE) {
-            const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias;
+            const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias &&
+                                !p.lo_off16 && !p.ldc16;
             if (simple && p.act == ACT_NONE)
                 run(std::integral_constant<int, 1>());
             else if (simple && p.act == ACT_GELU)

@@ -23,6 +23,9 @@ struct WeightSlot {
     PackKind kind;
     size_t offset = 0, bytes = 0;
     bool loaded = false;
+    // the K axis is stored twice, [W | W] per row / per tap: the consumer reads a split [hi | lo] activation
+    // operand of twice the depth (pipeline.hip, "split operands")
+    bool dup = false;
     int64_t numel() const {
         int64_t n = 1;
         for (auto d : dims) n *= d;
@@ -70,6 +73,18 @@ struct ModelW {
     const float *fov_lin_b, *fov_down_b, *fov_h0_b, *fov_h2_b, *fov_h4_w, *fov_h4_b;
 };
 
+// Split operands.  Every 16-bit MFMA operand costs one rounding of 2^-11 relative; on the un-diluted chain
+// tokens -> upsample convs -> ... -> fusion out_conv -> head (no residual path beside it) those roundings are
+// most of the depth error against the fp32 reference.  A stage listed here stores its 16-bit outputs as
+// hi = T(v), lo = T(v - hi) in twice the channels, and its consumer runs the same kernel over K' = 2K against
+// [W | W]: the product sees v to ~2^-22 at twice the MFMA work of that (small) layer.
+enum SplitStage : int32_t {
+    SPLIT_UPSAMPLE = 1,  // encoder.rs:307-325 upsample_* / upsample_lowres / fuse_lowres (A operands from merge)
+    SPLIT_FUSION_OUT = 2,  // decoder.rs:95-101 deconv + out_conv of every fusion block
+    SPLIT_HEAD = 4,        // mod.rs:323-333 head convs
+    SPLIT_DEC_CONVS = 8    // decoder.rs:189-195 convs[i-1] on the encodings
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -81,13 +96,11 @@ struct DevBuf {
 struct me_ctx {
     int device = 0;
     int32_t dtype = ME_DTYPE_F16;
+    // Stages whose 16-bit activation operands are carried as hi + lo pairs (me::SplitStage bits)
+    int32_t split_mask = 0;
+    bool split(int stage_bit) const { return (split_mask & stage_bit) != 0; }
     me_model_config cfg;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    // The two single-window ViTs (image encoder, FOV encoder: M = 577 GEMMs that cannot fill the chip)
-    // run on side streams beside the 35-window patch encoder.
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_img = nullptr, ev_fov = nullptr;
-    bool side_joined = false;  // this step's small ViTs ran on the launch stream: nothing to join
     std::string last_error;
     me_progress_fn progress = nullptr;
     void* progress_user = nullptr;
@@ -101,6 +114,7 @@ struct me_ctx {
     size_t arena_bytes = 0;
     bool finalized = false;
     me::ModelW w;
+    std::vector<std::string> unused_weights;  // checkpoint keys me_load_checkpoint_pt skipped
 
     // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
     std::map<std::string, me::DevBuf> bufs;
@@ -120,6 +134,7 @@ void resolve_weights(me_ctx* ctx);
 void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight_dtype,
                  const int64_t* dims, int32_t ndim);
 void finalize_weights(me_ctx* ctx);
+void load_checkpoint_pt(me_ctx* ctx, const char* path);
 
 // persistent device buffer for a pipeline site; zero-filled when (re)allocated
 void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes);
@@ -142,11 +157,12 @@ struct VitTaps {
 void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const VitTaps& taps,
                  void* final16, float* final32, const std::string& tag, hipStream_t stream);
 
-// fov_async: also start the FOV encoder (ViT + linear) on a side stream; stage_fov_tail joins it
-void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async);
+// with_fov: the FOV encoder (fov.rs:57-63 ViT + Linear) runs as a third row segment of the encoder's ViT
+// launches; stage_fov_tail finishes it
+void stage_encoder(me_ctx* ctx, const float* img32, int B, bool with_fov);
 void stage_decoder(me_ctx* ctx, int B, bool want_features32);
 void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s);
-void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev, bool join_side_stream);
+void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev);
 // f_norm_dev [B]; clamp 0 = canonical (no clamp, f_norm ignored -> 1)
 void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
 

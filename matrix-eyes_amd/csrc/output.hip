@@ -80,12 +80,16 @@ __device__ __forceinline__ float interpolate_point(const float* __restrict__ dat
 // only ever points backwards, so it is resolved by pointer jumping in LDS (<= log2(W) rounds)
 // followed by one gather from the noise row.  A source index >= x (possible only for degenerate
 // amplitudes) reads the not-yet-overwritten noise, exactly like the sequential loop.
+// range_dev: the depth range left on the device by clamp_minmax_kernel ({min, max}), read instead of the two
+// scalars when not null -- DepthMap::new -> output_stereogram chained without a host round trip
 __global__ __launch_bounds__(256) void stereogram_kernel(const float* __restrict__ depth, int rows,
                                                          int cols, float min_depth, float max_depth,
+                                                         const float* __restrict__ range_dev,
                                                          int out_w, int out_h, float amplitude,
                                                          const uint8_t* __restrict__ noise,
                                                          uint8_t* __restrict__ out, int rounds) {
     extern __shared__ int lds[];
+    if (range_dev) min_depth = range_dev[0], max_depth = range_dev[1];
     int* nxt = lds;            // [out_w] current ancestor
     int* term = lds + out_w;   // [out_w] noise index of a terminal pixel
     const int y = blockIdx.x;
@@ -144,8 +148,10 @@ __device__ __forceinline__ uint8_t map_color(int channel, float value) {
 }
 
 __global__ void depthmap_rgb_kernel(const float* __restrict__ depth, int64_t count, float min_depth,
-                                    float max_depth, uint8_t* __restrict__ rgb) {
+                                    float max_depth, const float* __restrict__ range_dev,
+                                    uint8_t* __restrict__ rgb) {
     // output.rs:128-131
+    if (range_dev) min_depth = range_dev[0], max_depth = range_dev[1];
     const float range = __fsub_rn(max_depth, min_depth);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -395,8 +401,9 @@ inline unsigned grid_for(int64_t total) {
 }  // namespace
 
 void depth_clamp_minmax_launch(float* depth, int64_t count, float* minmax_dev, hipStream_t stream) {
-    const unsigned init[2] = {0x7f800000u, 0u};  // +inf, 0
-    ME_HIP(hipMemcpyAsync(minmax_dev, init, sizeof init, hipMemcpyHostToDevice, stream));
+    // {+inf, 0} as bit patterns, set on the stream without host memory (graph-capturable, no staging copy)
+    ME_HIP(hipMemsetD32Async((hipDeviceptr_t)minmax_dev, 0x7f800000, 1, stream));
+    ME_HIP(hipMemsetD32Async((hipDeviceptr_t)(minmax_dev + 1), 0, 1, stream));
     unsigned g = grid_for(count);
     g = g > 2048 ? 2048 : g;
     hipLaunchKernelGGL(clamp_minmax_kernel, dim3(g), dim3(256), 0, stream, depth, count,
@@ -405,7 +412,7 @@ void depth_clamp_minmax_launch(float* depth, int64_t count, float* minmax_dev, h
 }
 
 void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min_depth,
-                       float max_depth, int32_t out_w, int32_t out_h, float amplitude,
+                       float max_depth, const float* range_dev, int32_t out_w, int32_t out_h, float amplitude,
                        const uint8_t* noise, uint8_t* out, hipStream_t stream) {
     ME_CHECK(out_w > 0 && out_h > 0 && rows > 0 && cols > 0, ME_ERR_BAD_SHAPE,
              "stereogram: %dx%d from %dx%d", out_w, out_h, rows, cols);
@@ -420,14 +427,14 @@ void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min
         attr_set = true;
     }
     hipLaunchKernelGGL(stereogram_kernel, dim3(out_h), dim3(256), lds, stream, depth, rows, cols,
-                       min_depth, max_depth, out_w, out_h, amplitude, noise, out, rounds);
+                       min_depth, max_depth, range_dev, out_w, out_h, amplitude, noise, out, rounds);
     ME_HIP(hipGetLastError());
 }
 
 void depthmap_rgb_launch(const float* depth, int64_t count, float min_depth, float max_depth,
-                         uint8_t* rgb, hipStream_t stream) {
+                         const float* range_dev, uint8_t* rgb, hipStream_t stream) {
     hipLaunchKernelGGL(depthmap_rgb_kernel, dim3(grid_for(count)), dim3(256), 0, stream, depth,
-                       count, min_depth, max_depth, rgb);
+                       count, min_depth, max_depth, range_dev, rgb);
     ME_HIP(hipGetLastError());
 }
 

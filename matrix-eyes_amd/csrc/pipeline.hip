@@ -67,12 +67,19 @@ GemmParams base_params() {
     return p;
 }
 
+// Split operands (model.h SplitStage): a_split: A holds [hi | lo] rows of 2K and W is stored [W | W];
+// out_split: the 16-bit output is written as [hi | lo] rows of 2N.
+void set_out16_split(GemmParams& p, int64_t C) { p.ldc16 = 2 * C, p.lo_off16 = (int32_t)C; }
+
 // out = act(A[M][K] . W[N][K]^T + bias) as 16-bit and/or f32 rows of stride ldc
 void linear(me_ctx* ctx, const void* A, int64_t M, int K, const void* W, int N, const float* bias,
-            void* out16, float* out32, int64_t ldc, int act, hipStream_t s) {
+            void* out16, float* out32, int64_t ldc, int act, hipStream_t s, bool a_split = false,
+            bool out_split = false) {
     GemmParams p = base_params();
-    p.M = (int)M, p.N = N, p.K = K, p.A = A, p.lda = K, p.W = W, p.bias = bias;
+    const int Kx = a_split ? 2 * K : K;
+    p.M = (int)M, p.N = N, p.K = Kx, p.A = A, p.lda = Kx, p.W = W, p.bias = bias;
     p.out16 = out16, p.out32 = out32, p.ldc = ldc, p.act = act;
+    if (out_split) set_out16_split(p, N);
     gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
 }
 
@@ -80,6 +87,7 @@ struct ConvOut {
     float* out32 = nullptr;   // [B*H*W][Cout]
     void* out16 = nullptr;    // 16-bit copy
     bool border16 = false;    // out16 is [B][H+2][W+2][Cout]
+    bool split16 = false;     // out16 pixels are [hi | lo] of 2*Cout
     int act = ACT_NONE;       // applied to out16 (and out32 unless act16_only)
     bool act16_only = true;
     const float* res32 = nullptr;
@@ -88,40 +96,55 @@ struct ConvOut {
 
 // Conv2d k x k (k = 1 or 3, pad (k-1)/2, stride 1 or 2) on a zero-bordered NHWC operand
 void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, const void* W, int Cout,
-          int k, int stride, const float* bias, const ConvOut& o, hipStream_t s) {
+          int k, int stride, const float* bias, const ConvOut& o, hipStream_t s, bool a_split = false) {
     GemmParams p = base_params();
     const int Ho = Hin / stride, Wo = Win / stride;
+    if (a_split) Cin *= 2;  // pixels of [hi | lo]; the packed weights repeat each tap's Cin values
     p.M = B * Ho * Wo, p.N = Cout, p.K = k * k * Cin;
     p.A = in16b, p.in_Hp = Hin + 2, p.in_Wp = Win + 2, p.Cin = Cin;
     p.out_H = Ho, p.out_W = Wo, p.KH = k, p.KW = k, p.stride = stride;
     p.W = W, p.bias = bias, p.res32 = o.res32, p.res32b = o.res32b;
     p.out32 = o.out32, p.out16 = o.out16, p.ldc = Cout, p.out16_border = o.border16 ? 1 : 0;
     p.act = o.act, p.act16_only = o.act16_only ? 1 : 0;
+    if (o.split16) set_out16_split(p, Cout);
     gemm_launch(p, A_CONV, EPI_STORE, ctx->dtype, s);
 }
 
 // ConvTranspose2d(2,2,stride 2) of an unbordered NHWC operand [B*H*W][Cin] -> [B][2H][2W][Cout]
+// pixel_stride: channels per pixel of out16 when it is a slice of a wider map (0: Cout, or 2 Cout when split);
+// out_split: out16 pixels are [hi | lo], the lo part lo_off channels after the hi part (0: Cout)
 void convt(me_ctx* ctx, const void* in16, int B, int H, int W_, int Cin, const void* W, int Cout,
            const float* bias, float* out32, void* out16, bool border16, int64_t pixel_stride,
-           int act16, hipStream_t s) {
+           int act16, hipStream_t s, bool a_split = false, bool out_split = false, int64_t lo_off = 0) {
     GemmParams p = base_params();
-    p.M = B * H * W_, p.N = 4 * Cout, p.K = Cin, p.A = in16, p.lda = Cin, p.W = W, p.bias = bias;
+    const int Kx = a_split ? 2 * Cin : Cin;
+    p.M = B * H * W_, p.N = 4 * Cout, p.K = Kx, p.A = in16, p.lda = Kx, p.W = W, p.bias = bias;
     p.out_H = H, p.out_W = W_, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
-    p.out16_border = border16 ? 1 : 0, p.ldc = pixel_stride ? pixel_stride : Cout, p.act = act16;
+    p.out16_border = border16 ? 1 : 0, p.ldc = Cout, p.act = act16;
+    if (out_split) {
+        p.lo_off16 = (int32_t)(lo_off ? lo_off : Cout);
+        p.ldc16 = pixel_stride ? pixel_stride : 2 * Cout;
+    } else if (pixel_stride) {
+        p.ldc16 = pixel_stride;
+    }
     gemm_launch(p, A_PLAIN, EPI_CONVT, ctx->dtype, s);
 }
 
 size_t bordered_bytes(int B, int H, int W, int C) { return (size_t)B * (H + 2) * (W + 2) * C * 2; }
 
 // encoder.rs:210-216 forward_seq over an upsample block: 1x1 conv (no bias) then ConvT x n.
-// The last ConvT writes the caller's outputs.
+// The last ConvT writes the caller's outputs.  With SPLIT_UPSAMPLE the input and every intermediate are
+// [hi | lo] operands; last_split / last_lo_off say whether (and where) the last 16-bit output is split too.
 void run_upsample(me_ctx* ctx, const std::string& tag, const void* in16, int B, int H,
                   const UpsampleW& u, float* last32, void* last16, bool last_border,
-                  int64_t last_pixel_stride, int last_act16, hipStream_t s) {
+                  int64_t last_pixel_stride, int last_act16, hipStream_t s, bool last_split = false,
+                  int64_t last_lo_off = 0) {
     const int C = ctx->C();
+    const bool sp = ctx->split(SPLIT_UPSAMPLE);
     const int64_t M = (int64_t)B * H * H;
-    void* a = site_buf(ctx, tag + ".proj", (size_t)M * u.dim_int * 2);
-    linear(ctx, in16, M, C, u.conv, u.dim_int, nullptr, a, nullptr, u.dim_int, ACT_NONE, s);
+    const size_t wide = sp ? 2 : 1;
+    void* a = site_buf(ctx, tag + ".proj", (size_t)M * u.dim_int * 2 * wide);
+    linear(ctx, in16, M, C, u.conv, u.dim_int, nullptr, a, nullptr, u.dim_int, ACT_NONE, s, sp, sp);
     const void* cur = a;
     int h = H;
     const int n = (int)u.convt.size();
@@ -129,12 +152,12 @@ void run_upsample(me_ctx* ctx, const std::string& tag, const void* in16, int B, 
         const bool last = i == n - 1;
         if (last) {
             convt(ctx, cur, B, h, h, u.cin[i], u.convt[i], u.cout[i], nullptr, last32, last16,
-                  last_border, last_pixel_stride, last_act16, s);
+                  last_border, last_pixel_stride, last_act16, s, sp, last_split, last_lo_off);
         } else {
             void* t = site_buf(ctx, tag + ".up" + std::to_string(i),
-                               (size_t)B * 4 * h * h * u.cout[i] * 2);
+                               (size_t)B * 4 * h * h * u.cout[i] * 2 * wide);
             convt(ctx, cur, B, h, h, u.cin[i], u.convt[i], u.cout[i], nullptr, nullptr, t, false, 0,
-                  ACT_NONE, s);
+                  ACT_NONE, s, sp, sp);
             cur = t;
         }
         h *= 2;
@@ -156,7 +179,7 @@ void tap_fn(void* user, int index, const float* tokens) {
                                                 : (index == ctx->cfg.tap_blocks[1] ? t->lat1 : nullptr);
     if (dst)
         merge_launch(tokens, nullptr, dst, t->B, 35, 0, 5, ctx->g() / 8, ctx->g(), ctx->C(),
-                     ctx->dtype, t->s);
+                     ctx->dtype, t->s, ctx->split(SPLIT_UPSAMPLE) ? 1 : 0);
 }
 
 }  // namespace
@@ -242,6 +265,7 @@ struct MergedVit {
     int64_t R0, seg1, seg2, Rtot;  // seg2 == 0 without the FOV encoder
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
+    float* fin32 = nullptr;
     RowSegs segs;
 
     static int64_t pad256(int64_t r) { return (r + 255) / 256 * 256; }
@@ -325,12 +349,16 @@ struct MergedVit {
     }
 
     // vit.rs:343 final norm of each ViT; the 16-bit results of segments 0 / 1 / 2
-    void finish() {
+    // want32: also keep the normalised tokens in f32 (the source of split [hi | lo] token maps)
+    void finish(bool want32) {
         set_ln(v1.norm_w, v1.norm_b, v2.norm_w, v2.norm_b);
-        layernorm_launch(tok, v0.norm_w, v0.norm_b, fin16, nullptr, Rtot, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s,
+        fin32 = want32 ? (float*)site_buf(ctx, "vitm.final32", (size_t)Rtot * ctx->C() * 4) : nullptr;
+        layernorm_launch(tok, v0.norm_w, v0.norm_b, fin16, fin32, Rtot, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s,
                          &segs);
     }
-    void* final16(int seg) const { return fin16 + (seg == 0 ? 0 : (seg == 1 ? seg1 : seg2)) * ctx->C() * 2; }
+    int64_t seg_row(int seg) const { return seg == 0 ? 0 : (seg == 1 ? seg1 : seg2); }
+    void* final16(int seg) const { return fin16 + seg_row(seg) * ctx->C() * 2; }
+    const float* final32(int seg) const { return fin32 + seg_row(seg) * ctx->C(); }
 };
 }  // namespace
 
@@ -342,12 +370,15 @@ void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const Vit
 }
 
 // encoder.rs:218-335 DepthProEncoder::forward_encodings
-void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
+void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async /* = with_fov */) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), S = ctx->S(), C = ctx->C(), P = ctx->P(), T = ctx->T();
     const int dec = c.dec_dim, e0 = c.enc_dims[0], e1 = c.enc_dims[1], e2 = c.enc_dims[2],
               e3 = c.enc_dims[3];
+    const bool sp = ctx->split(SPLIT_UPSAMPLE);  // merged token maps and upsample intermediates as [hi | lo]
+    const bool sp_dec = ctx->split(SPLIT_DEC_CONVS);  // encodings 1..4 as [hi | lo] for decoder.convs
+    const size_t wide = sp ? 2 : 1, wide_dec = sp_dec ? 2 : 1;
     report(ctx, 0.0f, "creating image pyramid");
     // encoder.rs:125-140 create_pyramid (x0 itself only changes type)
     void* x0 = site_buf(ctx, "enc.x0", (size_t)B * 3 * S * S * 2);
@@ -356,8 +387,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     cast_f32_to_16_launch(img32, x0, (int64_t)B * 3 * S * S, ctx->dtype, s);
     bilinear_launch(img32, x1, 3 * B, S, S / 2, c.align_corners, ctx->dtype, s);
     bilinear_launch(img32, x2, 3 * B, S, S / 4, c.align_corners, ctx->dtype, s);
-    ME_HIP(hipEventRecord(ctx->ev_fork, s));
-    void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2);
+    void* xg = site_buf(ctx, "enc.xg", (size_t)B * g * g * C * 2 * wide);
     // encoder.rs:238-250 split + cat, vit.rs:210-223 patch embed im2col
     report(ctx, 0.02f, "preparing image patches");
     void* patches = site_buf(ctx, "enc.patches", (size_t)B * 35 * P * 768 * 2);
@@ -365,81 +395,37 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
 
     report(ctx, 0.03f, "encoding patches");
     const int side0 = 4 * g, side1 = 2 * g;
-    void* lat0 = site_buf(ctx, "enc.lat0", (size_t)B * side0 * side0 * C * 2);
-    void* lat1 = site_buf(ctx, "enc.lat1", (size_t)B * side0 * side0 * C * 2);
-    void* tok16 = site_buf(ctx, "enc.tok16", (size_t)B * 35 * T * C * 2);
+    void* lat0 = site_buf(ctx, "enc.lat0", (size_t)B * side0 * side0 * C * 2 * wide);
+    void* lat1 = site_buf(ctx, "enc.lat1", (size_t)B * side0 * side0 * C * 2 * wide);
     TapCtx tc{ctx, B, lat0, lat1, s};
     VitTaps taps;
     taps.fn = tap_fn, taps.user = &tc;
-    // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend
-    // only on x2, so they run on the side streams beside the patch encoder.  The three ViTs are ISSUED
-    // block by block in turn: the side chains are the last thing the decoder waits for, so they must not
-    // start a whole patch-encoder's worth of host launches late, and the launch stream must not sit empty
-    // while ~350 small side launches are issued either (it did: 3.8 ms of the step in a rocprofv3 trace).
-    static const bool side_streams = getenv("ME_SIDE_STREAMS") != nullptr;  // the earlier arrangement
-    ctx->side_joined = !side_streams;
-    void* tokg16 = nullptr;
-    void* fov_tok16 = nullptr;
-    if (!side_streams) {
-        // one row space for the three ViTs on the launch stream (MergedVit above)
-        void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
-        patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s);  // both small ViTs embed the same patches
-        if (fov_async) report(ctx, 0.03f, "encoding fov");
-        MergedVit run(ctx, B, fov_async, patches, patches2, patches2, taps, s);
-        for (int i = 0; i < c.depth; ++i) run.block(i);
-        run.finish();
-        tok16 = run.final16(0), tokg16 = run.final16(1), fov_tok16 = fov_async ? run.final16(2) : nullptr;
-        merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s);
-        if (fov_async) {
-            float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
-            linear(ctx, fov_tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
-                   dec / 2, ACT_NONE, s);
-        }
-    } else {
-    hipStream_t s1 = ctx->side[0], s2 = ctx->side[1];
-    ME_HIP(hipStreamWaitEvent(s1, ctx->ev_fork, 0));
+    // encoder.rs:298-303 image encoder on the 1/4 image and (fov.rs:57-63) the FOV encoder: both depend only
+    // on x2; the three ViTs run as one row space on the launch stream (MergedVit above)
     void* patches2 = site_buf(ctx, "enc.patches2", (size_t)B * P * 768 * 2);
-    patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s1);
-    tokg16 = site_buf(ctx, "enc.tokg16", (size_t)B * T * C * 2);
-    if (fov_async) {  // stage_fov_vit, issued in step with the others
-        ME_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        report(ctx, 0.03f, "encoding fov");
-        void* fpatches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
-        patchify_windows_launch(x2, fpatches, B, g, ctx->dtype, s2);
-        fov_tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
-    }
-    {
-        VitRun main_run(ctx, ME_VIT_PATCH_ENCODER, patches, 35 * B, taps, "vit.patch", s);
-        VitRun img_run(ctx, ME_VIT_IMAGE_ENCODER, patches2, B, VitTaps(), "vit.image", s1);
-        std::unique_ptr<VitRun> fov_run;
-        if (fov_async)
-            fov_run.reset(new VitRun(ctx, ME_VIT_FOV_ENCODER, ctx->bufs.at("fov.patches").p, B, VitTaps(), "vit.fov", s2));
-        for (int i = 0; i < c.depth; ++i) {
-            main_run.block(i);
-            img_run.block(i);
-            if (fov_run) fov_run->block(i);
-        }
-        main_run.finish(tok16, nullptr);
-        img_run.finish(tokg16, nullptr);
-        if (fov_run) fov_run->finish(fov_tok16, nullptr);
-    }
-    merge_launch(nullptr, tokg16, xg, B, 1, 0, 1, 0, g, C, ctx->dtype, s1);
-    ME_HIP(hipEventRecord(ctx->ev_img, s1));
+    patchify_windows_launch(x2, patches2, B, g, ctx->dtype, s);  // both small ViTs embed the same patches
+    if (fov_async) report(ctx, 0.03f, "encoding fov");
+    MergedVit run(ctx, B, fov_async, patches, patches2, patches2, taps, s);
+    for (int i = 0; i < c.depth; ++i) run.block(i);
+    run.finish(sp);
+    // the final tokens feed merge: as 16-bit rows, or (split operands) as f32 rows that merge splits
+    const float* tok32 = sp ? run.final32(0) : nullptr;
+    const void* tok16 = sp ? nullptr : run.final16(0);
+    merge_launch(sp ? run.final32(1) : nullptr, sp ? nullptr : run.final16(1), xg, B, 1, 0, 1, 0, g, C, ctx->dtype,
+                 s, sp);
     if (fov_async) {
         float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
-        linear(ctx, fov_tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
-               dec / 2, ACT_NONE, s2);
-        ME_HIP(hipEventRecord(ctx->ev_fov, s2));
-    }
+        linear(ctx, run.final16(2), (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
+               dec / 2, ACT_NONE, s);
     }
     report(ctx, 0.55f, "reshaping patch encodings");
     // encoder.rs:263,285-294: split_with_sizes + merge
-    void* x0f = site_buf(ctx, "enc.x0f", (size_t)B * side0 * side0 * C * 2);
-    void* x1f = site_buf(ctx, "enc.x1f", (size_t)B * side1 * side1 * C * 2);
-    void* x2f = site_buf(ctx, "enc.x2f", (size_t)B * g * g * C * 2);
-    merge_launch(nullptr, tok16, x0f, B, 35, 0, 5, g / 8, g, C, ctx->dtype, s);
-    merge_launch(nullptr, tok16, x1f, B, 35, 25, 3, g / 4, g, C, ctx->dtype, s);
-    merge_launch(nullptr, tok16, x2f, B, 35, 34, 1, 0, g, C, ctx->dtype, s);
+    void* x0f = site_buf(ctx, "enc.x0f", (size_t)B * side0 * side0 * C * 2 * wide);
+    void* x1f = site_buf(ctx, "enc.x1f", (size_t)B * side1 * side1 * C * 2 * wide);
+    void* x2f = site_buf(ctx, "enc.x2f", (size_t)B * g * g * C * 2 * wide);
+    merge_launch(tok32, tok16, x0f, B, 35, 0, 5, g / 8, g, C, ctx->dtype, s, sp);
+    merge_launch(tok32, tok16, x1f, B, 35, 25, 3, g / 4, g, C, ctx->dtype, s, sp);
+    merge_launch(tok32, tok16, x2f, B, 35, 34, 1, 0, g, C, ctx->dtype, s, sp);
 
     report(ctx, 0.7f, "encoding features");
     // encoder.rs:307-316
@@ -448,27 +434,30 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async) {
     void* enc0_r16 = site_buf(ctx, "enc0.r16b", bordered_bytes(B, H0, H0, dec));
     run_upsample(ctx, "up_latent0", lat0, B, side0, ctx->w.up_latent0, enc0_32, enc0_r16, true, 0,
                  ACT_RELU, s);
-    void* enc1 = site_buf(ctx, "enc1.16b", bordered_bytes(B, H1, H1, e0));
+    void* enc1 = site_buf(ctx, "enc1.16b", bordered_bytes(B, H1, H1, e0) * wide_dec);
     run_upsample(ctx, "up_latent1", lat1, B, side0, ctx->w.up_latent1, nullptr, enc1, true, 0,
-                 ACT_NONE, s);
-    void* enc2 = site_buf(ctx, "enc2.16b", bordered_bytes(B, H2, H2, e1));
-    run_upsample(ctx, "up0", x0f, B, side0, ctx->w.up0, nullptr, enc2, true, 0, ACT_NONE, s);
-    void* enc3 = site_buf(ctx, "enc3.16b", bordered_bytes(B, H3, H3, e2));
-    run_upsample(ctx, "up1", x1f, B, side1, ctx->w.up1, nullptr, enc3, true, 0, ACT_NONE, s);
-    // encoder.rs:316-325: upsample2, upsample_lowres, cat on channels, fuse_lowres
-    char* cat = (char*)site_buf(ctx, "enc.cat", (size_t)B * H4 * H4 * 2 * e3 * 2);
-    run_upsample(ctx, "up2", x2f, B, g, ctx->w.up2, nullptr, cat, false, 2 * e3, ACT_NONE, s);
+                 ACT_NONE, s, sp_dec);
+    void* enc2 = site_buf(ctx, "enc2.16b", bordered_bytes(B, H2, H2, e1) * wide_dec);
+    run_upsample(ctx, "up0", x0f, B, side0, ctx->w.up0, nullptr, enc2, true, 0, ACT_NONE, s, sp_dec);
+    void* enc3 = site_buf(ctx, "enc3.16b", bordered_bytes(B, H3, H3, e2) * wide_dec);
+    run_upsample(ctx, "up1", x1f, B, side1, ctx->w.up1, nullptr, enc3, true, 0, ACT_NONE, s, sp_dec);
+    // encoder.rs:316-325: upsample2, upsample_lowres, cat on channels, fuse_lowres.  Split: a pixel of `cat`
+    // is [up2 hi | lowres hi | up2 lo | lowres lo], i.e. [hi(2 e3) | lo(2 e3)] against fuse_lowres' [W | W]
+    char* cat = (char*)site_buf(ctx, "enc.cat", (size_t)B * H4 * H4 * 2 * e3 * 2 * wide);
+    const int64_t cat_stride = 2 * e3 * (int64_t)wide;
+    run_upsample(ctx, "up2", x2f, B, g, ctx->w.up2, nullptr, cat, false, cat_stride, ACT_NONE, s, sp, 2 * e3);
     report(ctx, 0.9f, "upsampling lowres");
-    if (!ctx->side_joined) ME_HIP(hipStreamWaitEvent(s, ctx->ev_img, 0));  // join the image encoder
     convt(ctx, xg, B, g, g, C, ctx->w.up_lowres_w, e3, ctx->w.up_lowres_b, nullptr, cat + (size_t)e3 * 2,
-          false, 2 * e3, ACT_NONE, s);
+          false, cat_stride, ACT_NONE, s, sp, sp, 2 * e3);
     report(ctx, 0.95f, "fusing lowres");
-    void* enc4 = site_buf(ctx, "enc4.16b", bordered_bytes(B, H4, H4, e3));
+    void* enc4 = site_buf(ctx, "enc4.16b", bordered_bytes(B, H4, H4, e3) * wide_dec);
     {
         GemmParams p = base_params();
-        p.M = B * H4 * H4, p.N = e3, p.K = 2 * e3, p.A = cat, p.lda = 2 * e3, p.W = ctx->w.fuse_w;
+        const int K = 2 * e3 * (int)wide;
+        p.M = B * H4 * H4, p.N = e3, p.K = K, p.A = cat, p.lda = K, p.W = ctx->w.fuse_w;
         p.bias = ctx->w.fuse_b, p.out16 = enc4, p.out16_border = 1, p.ldc = e3;
         p.out_H = H4, p.out_W = H4;
+        if (sp_dec) set_out16_split(p, e3);
         gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
     }
 }
@@ -482,6 +471,8 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
     const int Cin[5] = {dec, c.enc_dims[0], c.enc_dims[1], c.enc_dims[2], c.enc_dims[3]};
     const char* enc_names[5] = {"enc0.r16b", "enc1.16b", "enc2.16b", "enc3.16b", "enc4.16b"};
 
+    const bool sp_dec = ctx->split(SPLIT_DEC_CONVS), spf = ctx->split(SPLIT_FUSION_OUT),
+               sp_head = ctx->split(SPLIT_HEAD);
     float* feat32 = nullptr;  // `features` carried between levels (f32 residual path)
     for (int i = 4; i >= 0; --i) {
         report(ctx, (4 - i) / 5.0f, i == 4 ? "decoding initial block" : "decoding blocks");
@@ -503,7 +494,7 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
             x1_r16 = site_buf(ctx, L + ".x1.r16b", nb);
             ConvOut o;
             o.out32 = x1_32, o.out16 = x1_r16, o.border16 = true, o.act = ACT_RELU;
-            conv(ctx, enc, B, h, h, Cin[i], ctx->w.dec_convs[i], dec, 3, 1, nullptr, o, s);
+            conv(ctx, enc, B, h, h, Cin[i], ctx->w.dec_convs[i], dec, 3, 1, nullptr, o, s, sp_dec);
         }
 
         float* out32;
@@ -530,31 +521,35 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
         ConvOut o3;
         o3.out16 = t2_r16, o3.border16 = true, o3.act = ACT_RELU;
         conv(ctx, out_r16, B, h, h, dec, fw.resnet2.w[0], dec, 3, 1, fw.resnet2.b[0], o3, s);
-        void* v16 = site_buf(ctx, L + ".v16", (size_t)B * h * h * dec * 2);
+        // the operands of deconv and out_conv have no residual path beside them: [hi | lo] under SPLIT_FUSION_OUT
+        const size_t wf = spf ? 2 : 1;
+        void* v16 = site_buf(ctx, L + ".v16", (size_t)B * h * h * dec * 2 * wf);
         ConvOut o4;
-        o4.out16 = v16, o4.res32 = out32;
+        o4.out16 = v16, o4.res32 = out32, o4.split16 = spf;
         conv(ctx, t2_r16, B, h, h, dec, fw.resnet2.w[1], dec, 3, 1, fw.resnet2.b[1], o4, s);
         // deconv (levels 1-4) then out_conv 1x1 (+bias)
         const void* pre = v16;
         int ho = h;
         if (fw.deconv) {
-            void* d16 = site_buf(ctx, L + ".d16", (size_t)B * 4 * h * h * dec * 2);
-            convt(ctx, v16, B, h, h, dec, fw.deconv, dec, nullptr, nullptr, d16, false, 0, ACT_NONE, s);
+            void* d16 = site_buf(ctx, L + ".d16", (size_t)B * 4 * h * h * dec * 2 * wf);
+            convt(ctx, v16, B, h, h, dec, fw.deconv, dec, nullptr, nullptr, d16, false, 0, ACT_NONE, s, spf, spf);
             pre = d16, ho = 2 * h;
         }
         const int64_t Mo = (int64_t)B * ho * ho;
         if (i > 0) {
             feat32 = (float*)site_buf(ctx, L + ".feat.f32", (size_t)Mo * dec * 4);
-            linear(ctx, pre, Mo, dec, fw.out_w, dec, fw.out_b, nullptr, feat32, dec, ACT_NONE, s);
+            linear(ctx, pre, Mo, dec, fw.out_w, dec, fw.out_b, nullptr, feat32, dec, ACT_NONE, s, spf);
         } else {
             // final features: 16-bit zero-bordered operand of head[0]; f32 copy for the ABI
             float* f32 = want_features32 ? (float*)site_buf(ctx, "features.f32", (size_t)Mo * dec * 4)
                                          : nullptr;
-            void* f16b = site_buf(ctx, "features.16b", bordered_bytes(B, ho, ho, dec));
+            void* f16b = site_buf(ctx, "features.16b", bordered_bytes(B, ho, ho, dec) * (sp_head ? 2 : 1));
             GemmParams p = base_params();
-            p.M = (int)Mo, p.N = dec, p.K = dec, p.A = pre, p.lda = dec, p.W = fw.out_w;
+            const int K = dec * (int)wf;
+            p.M = (int)Mo, p.N = dec, p.K = K, p.A = pre, p.lda = K, p.W = fw.out_w;
             p.bias = fw.out_b, p.out16 = f16b, p.out16_border = 1, p.out32 = f32, p.ldc = dec;
             p.out_H = ho, p.out_W = ho;
+            if (sp_head) set_out16_split(p, dec);
             gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
         }
     }
@@ -566,17 +561,21 @@ void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* 
     const me_model_config& c = ctx->cfg;
     const int dec = c.dec_dim, S = ctx->S(), Hh = S / 2;
     report(ctx, 0.0f, "forwarding head");
+    // mod.rs:323-333 is one chain without a residual path: its operands are [hi | lo] under SPLIT_HEAD
+    const bool sp = ctx->split(SPLIT_HEAD);
+    const size_t wide = sp ? 2 : 1;
     const void* f16b = ctx->bufs.at("features.16b").p;
-    void* h0 = site_buf(ctx, "head.h0", (size_t)B * Hh * Hh * (dec / 2) * 2);
+    void* h0 = site_buf(ctx, "head.h0", (size_t)B * Hh * Hh * (dec / 2) * 2 * wide);
     ConvOut o;
-    o.out16 = h0;
-    conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s);
-    void* h1 = site_buf(ctx, "head.h1b", bordered_bytes(B, S, S, dec / 2));
+    o.out16 = h0, o.split16 = sp;
+    conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s, sp);
+    void* h1 = site_buf(ctx, "head.h1b", bordered_bytes(B, S, S, dec / 2) * wide);
     convt(ctx, h0, B, Hh, Hh, dec / 2, ctx->w.head1_w, dec / 2, ctx->w.head1_b, nullptr, h1, true, 0,
-          ACT_NONE, s);
+          ACT_NONE, s, sp, sp);
     GemmParams p = base_params();
-    p.M = B * S * S, p.N = c.head_dims[0], p.K = 9 * (dec / 2);
-    p.A = h1, p.in_Hp = S + 2, p.in_Wp = S + 2, p.Cin = dec / 2, p.out_H = S, p.out_W = S;
+    const int hc = (dec / 2) * (int)wide;
+    p.M = B * S * S, p.N = c.head_dims[0], p.K = 9 * hc;
+    p.A = h1, p.in_Hp = S + 2, p.in_Wp = S + 2, p.Cin = hc, p.out_H = S, p.out_W = S;
     p.KH = 3, p.KW = 3, p.stride = 1, p.W = ctx->w.head2_w, p.bias = ctx->w.head2_b;
     p.w2 = ctx->w.head4_w, p.b2 = ctx->w.head4_b, p.f_norm = f_norm_dev;
     p.pixels_per_image = S * S, p.out32 = depth_dev;
@@ -592,21 +591,17 @@ void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s) {
     void* patches = site_buf(ctx, "fov.patches", (size_t)B * P * 768 * 2);
     patchify_windows_launch(x2, patches, B, g, ctx->dtype, s);
     void* tok16 = site_buf(ctx, "fov.tok16", (size_t)B * T * C * 2);
-#ifdef ME_DEBUG_HOOKS
-    if (!getenv("ME_DEBUG_SKIP_SIDE"))
-#endif
-        vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
+    vit_forward(ctx, ME_VIT_FOV_ENCODER, patches, B, VitTaps(), tok16, nullptr, "vit.fov", s);
     float* lin32 = (float*)site_buf(ctx, "fov.lin", (size_t)B * T * (dec / 2) * 4);
     linear(ctx, tok16, (int64_t)B * T, C, ctx->w.fov_lin_w, dec / 2, ctx->w.fov_lin_b, nullptr, lin32,
            dec / 2, ACT_NONE, s);
 }
 
 // fov.rs:66-88: the convolutional tail; needs "fov.lin" (stage_fov_vit) and "lowres.f32" (decoder)
-void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev, bool join_side_stream) {
+void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), P = ctx->P(), T = ctx->T(), dec = c.dec_dim;
-    if (join_side_stream && !ctx->side_joined) ME_HIP(hipStreamWaitEvent(s, ctx->ev_fov, 0));
     report(ctx, 0.85f, "fov lowres");
     const float* lin32 = (const float*)ctx->bufs.at("fov.lin").p;
     // fov.rs:70-74: relu(downsample[0](lowres)) + reshaped tokens

@@ -37,7 +37,9 @@ int32_t me_bcast_weights(me_ctx* ctx, const void* id128, int32_t rank, int32_t n
         if (rank == 0)
             ME_CHECK(ctx->finalized, ME_ERR_NOT_READY, "rank 0 must finalize its weights first");
         ME_HIP(hipSetDevice(ctx->device));
-        if (nranks > 1) {
+        {
+            // also with one rank: the communicator is created, the (in-place, root = self) broadcast runs and
+            // the communicator is destroyed, so a single-GPU box exercises every RCCL call of this path
             ncclUniqueId id;
             memcpy(&id, id128, sizeof id);
             ME_NCCL(ncclCommInitRank(&comm, nranks, id, rank));

@@ -7,6 +7,7 @@
 // multi-GPU job moves them with a single RCCL broadcast (rccl_bcast.hip).
 #include <cstring>
 
+#include "../host/pt_reader.hpp"
 #include "model.h"
 
 namespace me {
@@ -15,13 +16,15 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void add_slot(me_ctx* ctx, const std::string& name, std::vector<int64_t> dims, PackKind kind) {
+void add_slot(me_ctx* ctx, const std::string& name, std::vector<int64_t> dims, PackKind kind,
+              bool dup = false) {
     WeightSlot s;
     s.name = name;
     s.dims = std::move(dims);
     s.kind = kind;
     const bool f32 = kind == PK_VEC_F32 || kind == PK_CONVK_F32;
-    s.bytes = (size_t)s.numel() * (f32 ? 4 : 2);
+    s.dup = dup && !f32;
+    s.bytes = (size_t)s.numel() * (f32 ? 4 : 2) * (s.dup ? 2 : 1);
     s.offset = ctx->arena_bytes;
     ctx->arena_bytes = align_up(ctx->arena_bytes + s.bytes, 256);
     ctx->slot_by_name[name] = (int)ctx->slots.size();
@@ -57,10 +60,11 @@ void add_vit(me_ctx* ctx, const std::string& p) {
 
 // encoder.rs:85-118 init_project_upsample_block
 void add_upsample(me_ctx* ctx, const std::string& p, int64_t dim_out, int layers, int64_t dim_int) {
-    add_slot(ctx, p + "0.weight", {dim_int, ctx->C(), 1, 1}, PK_MAT_16);
+    const bool dup = ctx->split(SPLIT_UPSAMPLE);
+    add_slot(ctx, p + "0.weight", {dim_int, ctx->C(), 1, 1}, PK_MAT_16, dup);
     for (int i = 0; i < layers; ++i) {
         const int64_t in = i == 0 ? dim_int : dim_out;
-        add_slot(ctx, p + std::to_string(i + 1) + ".weight", {in, dim_out, 2, 2}, PK_CONVT_16);
+        add_slot(ctx, p + std::to_string(i + 1) + ".weight", {in, dim_out, 2, 2}, PK_CONVT_16, dup);
     }
 }
 
@@ -147,9 +151,22 @@ struct HostSrc {
     const void* p;
     int32_t dt;
     float get(int64_t i) const {
-        return dt == ME_WEIGHT_F32 ? ((const float*)p)[i] : half_to_float(((const uint16_t*)p)[i]);
+        switch (dt) {
+            case ME_WEIGHT_F32: return ((const float*)p)[i];
+            case ME_WEIGHT_F16: return half_to_float(((const uint16_t*)p)[i]);
+            case ME_WEIGHT_BF16: {
+                const uint32_t u = (uint32_t)((const uint16_t*)p)[i] << 16;
+                float f;
+                memcpy(&f, &u, 4);
+                return f;
+            }
+            default: return (float)((const double*)p)[i];
+        }
     }
 };
+size_t weight_elem_size(int32_t dt) {
+    return dt == ME_WEIGHT_F32 ? 4 : (dt == ME_WEIGHT_F64 ? 8 : 2);
+}
 
 }  // namespace
 
@@ -168,9 +185,9 @@ void build_weight_table(me_ctx* ctx) {
     add_upsample(ctx, "encoder.upsample0.", e1, 1, e1);
     add_upsample(ctx, "encoder.upsample1.", e2, 1, e2);
     add_upsample(ctx, "encoder.upsample2.", e3, 1, e3);
-    add_slot(ctx, "encoder.upsample_lowres.weight", {C, e3, 2, 2}, PK_CONVT_16);
+    add_slot(ctx, "encoder.upsample_lowres.weight", {C, e3, 2, 2}, PK_CONVT_16, ctx->split(SPLIT_UPSAMPLE));
     add_slot(ctx, "encoder.upsample_lowres.bias", {e3}, PK_VEC_F32);
-    add_slot(ctx, "encoder.fuse_lowres.weight", {e3, 2 * e3, 1, 1}, PK_MAT_16);
+    add_slot(ctx, "encoder.fuse_lowres.weight", {e3, 2 * e3, 1, 1}, PK_MAT_16, ctx->split(SPLIT_UPSAMPLE));
     add_slot(ctx, "encoder.fuse_lowres.bias", {e3}, PK_VEC_F32);
     // decoder.rs:115-146; dims_encoder = [dec, e0, e1, e2, e3] (mod.rs:293-295).  PyTorch keeps an
     // Identity at convs.0 when dims_encoder[0] == dim_decoder, so the file's keys start at convs.1
@@ -178,7 +195,7 @@ void build_weight_table(me_ctx* ctx) {
     ME_CHECK(dims_enc[0] == dec, ME_ERR_BAD_SHAPE, "decoder: dims_encoder[0] != dim_decoder");
     for (int i = 1; i < 5; ++i)
         add_slot(ctx, "decoder.convs." + std::to_string(i) + ".weight", {dec, dims_enc[i], 3, 3},
-                 PK_CONV_16);
+                 PK_CONV_16, ctx->split(SPLIT_DEC_CONVS));
     for (int i = 0; i < 5; ++i) {
         const std::string f = "decoder.fusions." + std::to_string(i) + ".";
         for (const char* rn : {"resnet1", "resnet2"})
@@ -186,16 +203,17 @@ void build_weight_table(me_ctx* ctx) {
                 add_slot(ctx, f + rn + ".residual." + idx + ".weight", {dec, dec, 3, 3}, PK_CONV_16);
                 add_slot(ctx, f + rn + ".residual." + idx + ".bias", {dec}, PK_VEC_F32);
             }
-        if (i != 0) add_slot(ctx, f + "deconv.weight", {dec, dec, 2, 2}, PK_CONVT_16);
-        add_slot(ctx, f + "out_conv.weight", {dec, dec, 1, 1}, PK_MAT_16);
+        if (i != 0) add_slot(ctx, f + "deconv.weight", {dec, dec, 2, 2}, PK_CONVT_16, ctx->split(SPLIT_FUSION_OUT));
+        add_slot(ctx, f + "out_conv.weight", {dec, dec, 1, 1}, PK_MAT_16, ctx->split(SPLIT_FUSION_OUT));
         add_slot(ctx, f + "out_conv.bias", {dec}, PK_VEC_F32);
     }
     // mod.rs:57-97 (PyTorch Sequential indices 0,1,2,4: index 3 is the ReLU)
-    add_slot(ctx, "head.0.weight", {dec / 2, dec, 3, 3}, PK_CONV_16);
+    const bool dup_head = ctx->split(SPLIT_HEAD);
+    add_slot(ctx, "head.0.weight", {dec / 2, dec, 3, 3}, PK_CONV_16, dup_head);
     add_slot(ctx, "head.0.bias", {dec / 2}, PK_VEC_F32);
-    add_slot(ctx, "head.1.weight", {dec / 2, dec / 2, 2, 2}, PK_CONVT_16);
+    add_slot(ctx, "head.1.weight", {dec / 2, dec / 2, 2, 2}, PK_CONVT_16, dup_head);
     add_slot(ctx, "head.1.bias", {dec / 2}, PK_VEC_F32);
-    add_slot(ctx, "head.2.weight", {c.head_dims[0], dec / 2, 3, 3}, PK_CONV_16);
+    add_slot(ctx, "head.2.weight", {c.head_dims[0], dec / 2, 3, 3}, PK_CONV_16, dup_head);
     add_slot(ctx, "head.2.bias", {c.head_dims[0]}, PK_VEC_F32);
     add_slot(ctx, "head.4.weight", {c.head_dims[1], c.head_dims[0], 1, 1}, PK_VEC_F32);
     add_slot(ctx, "head.4.bias", {c.head_dims[1]}, PK_VEC_F32);
@@ -262,7 +280,7 @@ void resolve_weights(me_ctx* ctx) {
 void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight_dtype,
                  const int64_t* dims, int32_t ndim) {
     ME_CHECK(name && data && dims, ME_ERR_BAD_ARG, "me_load_weight: null argument");
-    ME_CHECK(weight_dtype == ME_WEIGHT_F32 || weight_dtype == ME_WEIGHT_F16, ME_ERR_BAD_ARG,
+    ME_CHECK(weight_dtype >= ME_WEIGHT_F32 && weight_dtype <= ME_WEIGHT_F64, ME_ERR_BAD_ARG,
              "me_load_weight: bad weight dtype %d", weight_dtype);
     auto it = ctx->slot_by_name.find(name);
     ME_CHECK(it != ctx->slot_by_name.end(), ME_ERR_BAD_WEIGHT, "unexpected tensor '%s'", name);
@@ -277,7 +295,7 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
              want.c_str());
     }
     const int64_t n = s.numel();
-    const size_t src_bytes = (size_t)n * (weight_dtype == ME_WEIGHT_F32 ? 4 : 2);
+    const size_t src_bytes = (size_t)n * weight_elem_size(weight_dtype);
     std::vector<char> staged;
     if (is_device_ptr(data)) {
         staged.resize(src_bytes);
@@ -303,26 +321,36 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
                 for (int64_t i = 0; i < n; ++i) o[i] = src.get(i);
             break;
         }
+        // dup: every run of K (or Cin) source values is followed by a copy of itself: [W | W]
         case PK_MAT_16:
-            if (!to_bf16 && weight_dtype == ME_WEIGHT_F16)
+            if (s.dup) {
+                const int64_t N = s.dims[0], K = n / N;
+                for (int64_t r = 0; r < N; ++r)
+                    for (int64_t k = 0; k < K; ++k) put16(r * 2 * K + k, r * K + k), put16(r * 2 * K + K + k, r * K + k);
+            } else if (!to_bf16 && weight_dtype == ME_WEIGHT_F16) {
                 memcpy(packed.data(), data, (size_t)n * 2);
-            else
+            } else {
                 for (int64_t i = 0; i < n; ++i) put16(i, i);
+            }
             break;
         case PK_CONV_16: {  // [Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin]
             const int64_t Cout = s.dims[0], Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
+            const int64_t D = s.dup ? 2 : 1;
             for (int64_t co = 0; co < Cout; ++co)
                 for (int64_t ci = 0; ci < Cin; ++ci)
                     for (int64_t t = 0; t < kk; ++t)
-                        put16((co * kk + t) * Cin + ci, (co * Cin + ci) * kk + t);
+                        for (int64_t d = 0; d < D; ++d)
+                            put16((co * kk + t) * D * Cin + d * Cin + ci, (co * Cin + ci) * kk + t);
             break;
         }
         case PK_CONVT_16: {  // [Cin][Cout][2][2] -> [(dy*2+dx)*Cout + co][Cin]
             const int64_t Cin = s.dims[0], Cout = s.dims[1];
+            const int64_t D = s.dup ? 2 : 1;
             for (int64_t ci = 0; ci < Cin; ++ci)
                 for (int64_t co = 0; co < Cout; ++co)
                     for (int64_t q = 0; q < 4; ++q)
-                        put16((q * Cout + co) * Cin + ci, (ci * Cout + co) * 4 + q);
+                        for (int64_t d = 0; d < D; ++d)
+                            put16((q * Cout + co) * D * Cin + d * Cin + ci, (ci * Cout + co) * 4 + q);
             break;
         }
         case PK_CONVK_F32: {  // [1][Cin][k][k] -> f32 [k][k][Cin]
@@ -336,6 +364,33 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
     ME_HIP(hipMemcpy(ctx->arena + s.offset, packed.data(), s.bytes, hipMemcpyHostToDevice));
     s.loaded = true;
     ctx->finalized = false;
+}
+
+// mod.rs:229-249 load_record: PytorchStore::from_file + apply + the errors / missing checks
+void load_checkpoint_pt(me_ctx* ctx, const char* path) {
+    ME_CHECK(path, ME_ERR_BAD_ARG, "me_load_checkpoint_pt: null path");
+    ctx->unused_weights.clear();
+    try {
+        matrix_eyes::PtFile file(path);
+        for (const matrix_eyes::PtTensor& t : file.tensors()) {
+            // a key the model has no slot for is not an error (mod.rs:236-243 checks errors and missing only):
+            // state_dict wrapper siblings, EMA copies, integer buffers -- whatever their dtype
+            if (ctx->slot_by_name.find(t.name) == ctx->slot_by_name.end()) {
+                ctx->unused_weights.push_back(t.name);
+                continue;
+            }
+            int32_t wd;
+            if (t.dtype == "f16") wd = ME_WEIGHT_F16;
+            else if (t.dtype == "f32") wd = ME_WEIGHT_F32;
+            else if (t.dtype == "bf16") wd = ME_WEIGHT_BF16;
+            else if (t.dtype == "f64") wd = ME_WEIGHT_F64;
+            else fail(ME_ERR_BAD_WEIGHT, "%s: tensor %s has dtype %s", path, t.name.c_str(), t.dtype.c_str());
+            load_weight(ctx, t.name.c_str(), t.data, wd, t.dims.data(), (int32_t)t.dims.size());
+        }
+    } catch (const matrix_eyes::CheckpointError& err) {  // LoaderError::Pytorch
+        fail(ME_ERR_IO, "failed to load checkpoint: %s", err.what());
+    }
+    finalize_weights(ctx);
 }
 
 void finalize_weights(me_ctx* ctx) {

@@ -121,7 +121,7 @@ class Context:
             t = tensor.detach().contiguous()
             if t.dtype == torch.float16:
                 wd = L.ME_WEIGHT_F16
-            else:
+            else:   # bf16, f64, integer buffers: through f32
                 t, wd = t.to(torch.float32), L.ME_WEIGHT_F32
             ptr, shape, keep = C.c_void_p(t.data_ptr()), tuple(t.shape), t
         else:
@@ -136,11 +136,22 @@ class Context:
         del keep
 
     def load_state_dict(self, state: Dict[str, object]):
-        """Every tensor of `state` (extra keys are errors, like the Applier: mod.rs:238-240), then
-        me_weights_finalize (missing keys are errors: mod.rs:241-243)."""
+        """Every tensor of `state` the model has a slot for, then me_weights_finalize (missing keys are errors:
+        mod.rs:241-243).  Keys the model does not use are skipped and kept in `unused_keys`, as in the
+        reference: each of its four parts is applied from the full snapshot list and only `result.errors` and
+        `result.missing` are checked (mod.rs:236-243).  A tensor of the wrong shape stays an error."""
+        expected = {n for n, _ in self.expected_weights()}
+        self.unused_keys = [n for n in state if n not in expected]
         for name, t in state.items():
-            self.load_weight(name, t)
+            if name in expected:
+                self.load_weight(name, t)
         self._check(self.lib.me_weights_finalize(self._h))
+
+    def load_checkpoint_pt(self, path: str):
+        """me_load_checkpoint_pt: the library's own reader of `torch.save` archives (mod.rs:229-249)."""
+        self._check(self.lib.me_load_checkpoint_pt(self._h, os.fsencode(path)))
+        n = self.lib.me_unused_weight_count(self._h)
+        self.unused_keys = [self.lib.me_unused_weight_name(self._h, i).decode() for i in range(n)]
 
     def weight_arena_bytes(self) -> int:
         return int(self.lib.me_weight_arena_bytes(self._h))
@@ -288,7 +299,12 @@ class DepthProModelLoader:
     def context(self, device: int = 0, dtype: str = "f16") -> Context:
         if self._ctx is None:
             ctx = Context(device, dtype, self.cfg)
-            ctx.load_state_dict(self._state_dict())
+            if self.checkpoint_path in (None, "synthetic") or os.environ.get("ME_TORCH_LOAD"):
+                ctx.load_state_dict(self._state_dict())
+            else:
+                # the library maps and parses the .pt archive itself (me_load_checkpoint_pt); ME_TORCH_LOAD=1
+                # goes through torch.load instead
+                ctx.load_checkpoint_pt(self.checkpoint_path)
             self._ctx = ctx
         return self._ctx
 

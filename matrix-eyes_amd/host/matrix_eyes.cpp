@@ -7,7 +7,6 @@
 #include <random>
 
 #include "matrix_eyes_hip.h"
-#include "pt_reader.hpp"
 
 namespace matrix_eyes {
 
@@ -73,23 +72,11 @@ Device::~Device() {
 void DepthProModelLoader::ensure_loaded(const Device& device) const {
     if (device.weights_loaded_) return;
     me_ctx* ctx = device.ctx();
-    try {
-        PtFile file(checkpoint_path_);
-        for (const PtTensor& t : file.tensors()) {
-            int32_t wd;
-            if (t.dtype == "f16")
-                wd = ME_WEIGHT_F16;
-            else if (t.dtype == "f32")
-                wd = ME_WEIGHT_F32;
-            else
-                throw CheckpointError(checkpoint_path_ + ": tensor " + t.name + " has dtype " + t.dtype);
-            check_model(ctx, me_load_weight(ctx, t.name.c_str(), t.data, wd, t.dims.data(), (int32_t)t.dims.size()),
-                        "failed to load checkpoint");
-        }
-    } catch (const CheckpointError& err) {  // LoaderError::Pytorch
-        throw ModelError(ME_ERR_IO, std::string("Model error: failed to load checkpoint: ") + err.what());
-    }
-    check_model(ctx, me_weights_finalize(ctx), "failed to load checkpoint");
+    // mod.rs:229-249: the library reads the PyTorch archive itself; keys the model does not use are skipped
+    const int32_t rc = me_load_checkpoint_pt(ctx, checkpoint_path_.c_str());
+    if (rc == ME_ERR_IO)  // LoaderError::Pytorch
+        throw ModelError(ME_ERR_IO, std::string("Model error: ") + me_last_error(ctx));
+    check_model(ctx, rc, "failed to load checkpoint");
     (void)convert_checkpoints_;
     device.weights_loaded_ = true;
 }

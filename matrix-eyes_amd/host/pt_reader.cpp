@@ -22,8 +22,14 @@ struct Member {
     uint64_t size;
 };
 
-// ZIP central directory -> name -> stored bytes.  torch.save never compresses.
+// ZIP central directory -> name -> stored bytes.  torch.save never compresses.  Every offset comes from the
+// file: each read is checked against the mapped size first, in subtraction form so that a huge offset cannot
+// wrap the comparison.
 std::map<std::string, Member> zip_members(const uint8_t* f, size_t n, const std::string& path) {
+    auto fits = [n](uint64_t off, uint64_t len) { return len <= n && off <= n - len; };
+    auto need = [&](uint64_t off, uint64_t len, const char* what) {
+        if (!fits(off, len)) throw CheckpointError(path + ": " + what);
+    };
     if (n < 22) throw CheckpointError(path + ": not a zip archive");
     size_t eocd = n - 22;
     const size_t stop = n > 22 + 65535 ? n - 22 - 65535 : 0;
@@ -34,31 +40,42 @@ std::map<std::string, Member> zip_members(const uint8_t* f, size_t n, const std:
     uint64_t count = le16(f + eocd + 10), cd_off = le32(f + eocd + 16);
     if (eocd >= 20 && le32(f + eocd - 20) == 0x07064b50) {  // zip64 locator
         const uint64_t e64 = le64(f + eocd - 20 + 8);
-        if (e64 + 56 > n || le32(f + e64) != 0x06064b50) throw CheckpointError(path + ": bad zip64 record");
+        need(e64, 56, "bad zip64 record");
+        if (le32(f + e64) != 0x06064b50) throw CheckpointError(path + ": bad zip64 record");
         count = le64(f + e64 + 32), cd_off = le64(f + e64 + 48);
     }
+    if (count > n / 46) throw CheckpointError(path + ": bad zip central directory");
     std::map<std::string, Member> out;
     uint64_t p = cd_off;
     for (uint64_t i = 0; i < count; ++i) {
-        if (p + 46 > n || le32(f + p) != 0x02014b50) throw CheckpointError(path + ": bad zip central directory");
+        need(p, 46, "bad zip central directory");
+        if (le32(f + p) != 0x02014b50) throw CheckpointError(path + ": bad zip central directory");
         const uint16_t method = le16(f + p + 10), nlen = le16(f + p + 28), xlen = le16(f + p + 30), clen = le16(f + p + 32);
         uint64_t csize = le32(f + p + 20), usize = le32(f + p + 24), lho = le32(f + p + 42);
+        need(p + 46, (uint64_t)nlen + xlen + clen, "truncated zip central directory");
         const std::string name((const char*)f + p + 46, nlen);
         const uint8_t* x = f + p + 46 + nlen;  // zip64 extra field
-        for (uint16_t o = 0; o + 4 <= xlen;) {
+        for (uint32_t o = 0; o + 4 <= xlen;) {
             const uint16_t id = le16(x + o), sz = le16(x + o + 2);
+            if (o + 4 + (uint32_t)sz > xlen) throw CheckpointError(path + ": bad zip extra field");
             if (id == 1) {
-                const uint8_t* q = x + o + 4;
-                if (usize == 0xffffffffu) usize = le64(q), q += 8;
-                if (csize == 0xffffffffu) csize = le64(q), q += 8;
-                if (lho == 0xffffffffu) lho = le64(q), q += 8;
+                uint32_t q = o + 4;
+                const uint32_t end = o + 4 + sz;
+                auto take64 = [&](uint64_t& dst) {
+                    if (q + 8 > end) throw CheckpointError(path + ": bad zip64 extra field");
+                    dst = le64(x + q), q += 8;
+                };
+                if (usize == 0xffffffffu) take64(usize);
+                if (csize == 0xffffffffu) take64(csize);
+                if (lho == 0xffffffffu) take64(lho);
             }
             o += 4 + sz;
         }
         if (method != 0) throw CheckpointError(path + ": member " + name + " is compressed");
-        if (lho + 30 > n || le32(f + lho) != 0x04034b50) throw CheckpointError(path + ": bad zip local header");
+        need(lho, 30, "bad zip local header");
+        if (le32(f + lho) != 0x04034b50) throw CheckpointError(path + ": bad zip local header");
         const uint64_t start = lho + 30 + le16(f + lho + 26) + le16(f + lho + 28);
-        if (start + usize > n) throw CheckpointError(path + ": member " + name + " runs past the end of the file");
+        if (!fits(start, usize)) throw CheckpointError(path + ": member " + name + " runs past the end of the file");
         out[name] = Member{f + start, usize};
         p += 46 + (uint64_t)nlen + xlen + clen;
     }
@@ -141,6 +158,7 @@ public:
                 }
                 case 0x93: {                                             // STACK_GLOBAL
                     Ref name = pop(), mod = pop();
+                    if (name->kind != Value::STR || mod->kind != Value::STR) bad("STACK_GLOBAL without two strings");
                     Ref g = make(Value::GLOBAL);
                     g->s = mod->s, g->s2 = name->s;
                     push(g); break;
@@ -158,12 +176,14 @@ public:
                     for (int j = k - 1; j >= 0; --j) t->items[j] = pop();
                     push(t); break;
                 }
-                case 'a': { Ref v = pop(); top()->items.push_back(v); break; }
-                case 'e': { std::vector<Ref> v = pop_to_mark(); for (Ref& x : v) top()->items.push_back(x); break; }
-                case 's': { Ref v = pop(), k = pop(); top()->dict.emplace_back(k, v); break; }
+                // a container opcode applied to anything else (a damaged file) must not write into it
+                case 'a': { Ref v = pop(); list_top()->items.push_back(v); break; }
+                case 'e': { std::vector<Ref> v = pop_to_mark(); for (Ref& x : v) list_top()->items.push_back(x); break; }
+                case 's': { Ref v = pop(), k = pop(); dict_top()->dict.emplace_back(k, v); break; }
                 case 'u': {
                     std::vector<Ref> kv = pop_to_mark();
-                    for (size_t j = 0; j + 1 < kv.size(); j += 2) top()->dict.emplace_back(kv[j], kv[j + 1]);
+                    Ref& d = dict_top();
+                    for (size_t j = 0; j + 1 < kv.size(); j += 2) d->dict.emplace_back(kv[j], kv[j + 1]);
                     break;
                 }
                 case 'Q': push(persistent(pop())); break;                // BINPERSID
@@ -215,6 +235,17 @@ private:
         if (stack_.empty()) throw CheckpointError(path_ + ": pickle stack underflow");
         return stack_.back();
     }
+    [[noreturn]] void bad(const char* what) { throw CheckpointError(path_ + ": malformed pickle: " + what); }
+    // objects of classes this reader does not model are OPAQUE: items stored into them are dropped (the
+    // Value keeps them in vectors nothing reads); anything else is a damaged stream
+    Ref& list_top() {
+        if (top()->kind != Value::LIST && top()->kind != Value::OPAQUE) bad("APPEND(S) onto something that is not a list");
+        return top();
+    }
+    Ref& dict_top() {
+        if (top()->kind != Value::DICT && top()->kind != Value::OPAQUE) bad("SETITEM(S) onto something that is not a dict");
+        return top();
+    }
     Ref get(uint32_t k) {
         auto it = memo_.find(k);
         if (it == memo_.end()) throw CheckpointError(path_ + ": pickle memo miss");
@@ -231,7 +262,8 @@ private:
     }
     // ('storage', <class torch.XStorage>, key, location, numel)
     Ref persistent(const Ref& pid) {
-        if (pid->kind != Value::TUPLE || pid->items.size() < 3 || pid->items[0]->s != "storage")
+        if (pid->kind != Value::TUPLE || pid->items.size() < 3 || pid->items[0]->kind != Value::STR ||
+            pid->items[0]->s != "storage" || pid->items[1]->kind != Value::GLOBAL || pid->items[2]->kind != Value::STR)
             throw CheckpointError(path_ + ": unknown persistent id");
         const char* dt = storage_dtype(pid->items[1]->s2);
         if (!dt) throw CheckpointError(path_ + ": storage class " + pid->items[1]->s2 + " is not supported");
@@ -239,17 +271,22 @@ private:
         st->s = pid->items[2]->s, st->s2 = dt;
         return st;
     }
-    static std::vector<int64_t> ints(const Ref& t) {
+    std::vector<int64_t> ints(const Ref& t) {
+        if (t->kind != Value::TUPLE) bad("tensor size / stride is not a tuple");
         std::vector<int64_t> v;
-        for (const Ref& x : t->items) v.push_back(x->i);
+        for (const Ref& x : t->items) {
+            if (x->kind != Value::INT) bad("tensor size / stride entry is not an integer");
+            v.push_back(x->i);
+        }
         return v;
     }
     Ref reduce(const Ref& fn, const Ref& args) {
-        if (fn->kind == Value::GLOBAL) {
+        if (fn->kind == Value::GLOBAL && args->kind == Value::TUPLE) {
             if (fn->s == "collections" && fn->s2 == "OrderedDict") return make(Value::DICT);
             if (fn->s == "torch._utils" && fn->s2 == "_rebuild_tensor_v2" && args->items.size() >= 4) {
                 Ref t = make(Value::TENSOR);
                 t->storage = args->items[0];
+                if (args->items[1]->kind != Value::INT) bad("tensor storage offset is not an integer");
                 t->offset = args->items[1]->i;
                 t->dims = ints(args->items[2]), t->strides = ints(args->items[3]);
                 return t;
@@ -278,17 +315,24 @@ void collect(const Ref& v, const std::string& prefix, const std::map<std::string
             continue;
         }
         if (t->kind != Value::TENSOR || !t->storage || t->storage->kind != Value::STORAGE) continue;
-        int64_t expect = 1;
-        for (size_t d = t->dims.size(); d-- > 0;) {
-            if (t->dims[d] != 1 && t->strides[d] != expect)
-                throw CheckpointError(path + ": tensor " + name + " is not contiguous");
-            expect *= t->dims[d];
-        }
+        if (t->strides.size() != t->dims.size() || t->offset < 0)
+            throw CheckpointError(path + ": tensor " + name + " has a malformed size / stride / offset");
         auto it = members.find(root + "data/" + t->storage->s);
         if (it == members.end()) throw CheckpointError(path + ": storage " + t->storage->s + " of " + name + " is missing");
-        const size_t esz = dtype_size(t->storage->s2);
-        const size_t nbytes = (size_t)expect * esz, off = (size_t)t->offset * esz;
-        if (off + nbytes > it->second.size) throw CheckpointError(path + ": tensor " + name + " runs past its storage");
+        const uint64_t esz = dtype_size(t->storage->s2), cap = it->second.size / esz;  // elements the storage holds
+        uint64_t expect = 1;
+        for (size_t d = t->dims.size(); d-- > 0;) {
+            if (t->dims[d] < 0) throw CheckpointError(path + ": tensor " + name + " has a negative dimension");
+            if (t->dims[d] != 1 && t->strides[d] != (int64_t)expect)
+                throw CheckpointError(path + ": tensor " + name + " is not contiguous");
+            // the product stays <= cap (no overflow): a larger tensor cannot lie inside its storage anyway
+            if (t->dims[d] != 0 && expect > cap / (uint64_t)t->dims[d])
+                throw CheckpointError(path + ": tensor " + name + " runs past its storage");
+            expect *= (uint64_t)t->dims[d];
+        }
+        if ((uint64_t)t->offset > cap || expect > cap - (uint64_t)t->offset)
+            throw CheckpointError(path + ": tensor " + name + " runs past its storage");
+        const size_t nbytes = (size_t)(expect * esz), off = (size_t)((uint64_t)t->offset * esz);
         PtTensor e;
         e.name = name, e.dtype = t->storage->s2, e.dims = t->dims;
         e.data = it->second.data + off, e.nbytes = nbytes;
