@@ -46,6 +46,23 @@ int32_t me_op_conv2d(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32
 int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_t H, int32_t W,
                                 int32_t Cin, const void* w16, int32_t Cout, const float* bias,
                                 float* out32, void* out16, int32_t border16, int32_t tile_cfg);
+/* MX block-scaled fp8 (ME_DTYPE_FP8, BASELINE configs[3]; csrc/gemm_fp8.hip, mx_fp8.h).
+   me_op_quantize_fp8: f16 [rows][K] -> e4m3 bytes dst8 [rows][K] + one e8m0 scale per 32 K elements into
+   `scales`, in the weight operand's layout (weight_layout = 1: rows a multiple of 64, rows*K/32 bytes) or the
+   activation operand's (0: ceil(rows/128)*128*K/32 bytes).  me_op_scale_index gives the byte position of
+   (row, K block) in either layout, so that a test can read the scales back.
+   me_op_layernorm_fp8: LayerNorm with the result quantised as an activation operand.
+   me_op_linear_fp8: out = act(A8 . W8^T + bias) with M, N multiples of 256 and K a multiple of 128 (>= 256), as
+   ONE of: out16 (f16 [M][N]); out8 + out8_scale (GELU'd, quantised as the next GEMM's activation operand);
+   x32 (+ gamma): the residual update x += gamma * (A . W^T + bias). */
+int32_t me_op_quantize_fp8(me_ctx* ctx, const void* src16, int64_t rows, int32_t K, int32_t weight_layout,
+                           uint8_t* dst8, uint8_t* scales);
+int64_t me_op_scale_index(int64_t row, int32_t kblock, int64_t rows, int32_t weight_layout);
+int32_t me_op_layernorm_fp8(me_ctx* ctx, const float* x32, const float* weight, const float* bias, uint8_t* y8,
+                            uint8_t* yscale, int64_t rows, int32_t dim, float eps);
+int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                         const uint8_t* W8, const uint8_t* w_scale, const float* bias, void* out16, uint8_t* out8,
+                         uint8_t* out8_scale, const float* gamma, float* x32);
 /* f32 <-> context 16-bit type */
 int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
 int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);

@@ -11,5 +11,5 @@ __version__ = "0.1.0"
 from .config import ModelConfig, expected_weights  # noqa: F401
 from ._lib import MatrixEyesError, load_library, library_path  # noqa: F401
 from .depth_pro import Context, DepthProModelLoader, IMG_SIZE  # noqa: F401
-from .output import DepthMap, ImageOutputFormat, VertexMode  # noqa: F401
+from .output import DepthMap, DeviceDepthMap, ImageOutputFormat, VertexMode  # noqa: F401
 from .reconstruction import ReconstructionError, SourceImage, extract_depth  # noqa: F401

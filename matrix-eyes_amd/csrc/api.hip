@@ -8,6 +8,7 @@
 
 #include "../../include/matrix_eyes_hip_ops.h"
 #include "model.h"
+#include "mx_fp8.h"
 
 using namespace me;
 
@@ -117,8 +118,8 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
     *out = nullptr;
     me_ctx* ctx = nullptr;
     try {
-        ME_CHECK(dtype == ME_DTYPE_F16 || dtype == ME_DTYPE_BF16, ME_ERR_BAD_ARG, "bad dtype %d",
-                 dtype);
+        ME_CHECK(dtype == ME_DTYPE_F16 || dtype == ME_DTYPE_BF16 || dtype == ME_DTYPE_FP8, ME_ERR_BAD_ARG,
+                 "bad dtype %d", dtype);
         int ndev = 0;
         const hipError_t e = hipGetDeviceCount(&ndev);
         ME_CHECK(e == hipSuccess && ndev > 0, ME_ERR_HIP,
@@ -128,7 +129,9 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
                  ndev);
         ctx = new me_ctx();
         ctx->device = device_id;
-        ctx->dtype = dtype;
+        // fp8 contexts: every 16-bit operand is f16 (the checkpoint's own type), the big ViT linears are MX fp8
+        ctx->fp8 = dtype == ME_DTYPE_FP8;
+        ctx->dtype = ctx->fp8 ? ME_DTYPE_F16 : dtype;
         if (cfg)
             ctx->cfg = *cfg;
         else
@@ -136,6 +139,8 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         // diagnostic override of me_model_config.split_operands (tools/split_budget.py)
         if (const char* e = getenv("ME_SPLIT_OPERANDS")) ctx->cfg.split_operands = atoi(e);
         validate_config(ctx->cfg);
+        ME_CHECK(!ctx->fp8 || ctx->cfg.embed_dim % 256 == 0, ME_ERR_BAD_SHAPE,
+                 "ME_DTYPE_FP8 needs embed_dim a multiple of 256 (256x256 tiles, K slabs of 128): %d", ctx->cfg.embed_dim);
         ctx->split_mask = ctx->cfg.split_operands;  // model.h SplitStage bits
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -163,6 +168,7 @@ void me_ctx_destroy(me_ctx* ctx) {
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->arena8) (void)hipFree(ctx->arena8);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -237,6 +243,7 @@ void* me_weight_arena_ptr(const me_ctx* ctx) { return ctx ? (void*)ctx->arena : 
 int32_t me_weights_adopt(me_ctx* ctx) {
     ME_API_BEGIN(ctx)
     for (WeightSlot& s : ctx->slots) s.loaded = true;
+    build_fp8_weights(ctx);
     ctx->finalized = true;
     ME_API_END(ctx)
 }
@@ -699,6 +706,48 @@ int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_
     p.out_H = H, p.out_W = W, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
     p.out16_border = border16, p.ldc = Cout;
     gemm_launch(p, A_PLAIN, EPI_CONVT, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_quantize_fp8(me_ctx* ctx, const void* src16, int64_t rows, int32_t K, int32_t weight_layout,
+                           uint8_t* dst8, uint8_t* scales) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(src16 && dst8 && scales, ME_ERR_BAD_ARG, "me_op_quantize_fp8: null pointer");
+    quantize_f16_to_fp8_launch(src16, dst8, scales, rows, K, weight_layout, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int64_t me_op_scale_index(int64_t row, int32_t kblock, int64_t rows, int32_t weight_layout) {
+    return weight_layout ? w_scale_index(row, kblock, rows / 64) : a_scale_index(row, kblock, cdiv(rows, 128));
+}
+
+int32_t me_op_layernorm_fp8(me_ctx* ctx, const float* x32, const float* weight, const float* bias, uint8_t* y8,
+                            uint8_t* yscale, int64_t rows, int32_t dim, float eps) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(x32 && weight && bias && y8 && yscale, ME_ERR_BAD_ARG, "me_op_layernorm_fp8: null pointer");
+    layernorm_fp8_launch(x32, weight, bias, y8, yscale, rows, dim, eps, ctx->stream);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                         const uint8_t* W8, const uint8_t* w_scale, const float* bias, void* out16, uint8_t* out8,
+                         uint8_t* out8_scale, const float* gamma, float* x32) {
+    ME_API_BEGIN(ctx)
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = a_scale, p.a_mt = (int)cdiv(M, 128);
+    p.W = W8, p.w_scale = w_scale, p.bias = bias, p.ldc = N;
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    if (x32) {
+        ME_CHECK(gamma && bias, ME_ERR_BAD_ARG, "me_op_linear_fp8: the residual form takes bias and gamma");
+        p.gamma = gamma, p.res32 = x32, p.out32 = x32;
+        gemm_fp8_launch(p, EPI_RESID_SCALE, ctx->stream);
+    } else if (out8) {
+        p.act = ACT_GELU, p.out8 = out8, p.out8_scale = out8_scale, p.out8_mt = (int)cdiv(M, 128);
+        gemm_fp8_launch(p, EPI_STORE, ctx->stream);
+    } else {
+        p.out16 = out16;
+        gemm_fp8_launch(p, EPI_STORE, ctx->stream);
+    }
     ME_API_END(ctx)
 }
 

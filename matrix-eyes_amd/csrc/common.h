@@ -173,6 +173,12 @@ struct GemmParams {
     int32_t seg1, seg2;
     const void *W_s1, *W_s2;
     const float *bias_s1, *bias_s2, *gamma_s1, *gamma_s2;
+    // MX fp8 operands (gemm_fp8.hip): e8m0 block scales of A and W in the per-wave layouts of mx_fp8.h, a_mt =
+    // 128-row tiles of the A scale array; fp8 output (the next GEMM's A operand) with its scale array
+    const uint8_t *a_scale, *w_scale, *w_scale_s1, *w_scale_s2;
+    int32_t a_mt;
+    uint8_t *out8, *out8_scale;
+    int32_t out8_mt;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).
@@ -183,6 +189,11 @@ constexpr int kGemmQueueWords = 9 * 32;
 // dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).
 void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg = -1);
+// MX fp8 x fp8 (gemm_fp8.hip): EPI_STORE (f16 out16, or fp8 out8 + scales) / EPI_RESID_SCALE
+void gemm_fp8_launch(const GemmParams& p, EpiKind epi, hipStream_t stream);
+// f16 [rows][K] -> e4m3 + e8m0 scales in the weight (1) or activation (0) scale layout
+void quantize_f16_to_fp8_launch(const void* src16, uint8_t* dst8, uint8_t* scales, int64_t rows, int32_t K,
+                                int32_t weight_layout, hipStream_t stream);
 int gemm_num_configs();
 const char* gemm_config_name(int cfg);
 
@@ -207,6 +218,9 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
 // y16[r][:] = (x[r][:] - mean) / sqrt(var + eps) * w + b ; optional f32 copy y32.
 void layernorm_launch(const float* x, const float* w, const float* b, void* y16, float* y32,
                       int64_t rows, int32_t dim, float eps, int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr);
+// the same with the result quantised to MX fp8 (y8 [rows][dim] + block scales, activation layout)
+void layernorm_fp8_launch(const float* x, const float* w, const float* b, uint8_t* y8, uint8_t* yscale, int64_t rows,
+                          int32_t dim, float eps, hipStream_t stream, const RowSegs* segs = nullptr);
 // u8 HWC -> f32 NCHW, reconstruction.rs:114-124
 void preprocess_u8_launch(const uint8_t* rgb, float* img, int32_t batch, int32_t size,
                           hipStream_t stream);

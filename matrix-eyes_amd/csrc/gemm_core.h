@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mx_fp8.h"
 
 namespace me {
 
@@ -250,6 +251,7 @@ __device__ __forceinline__ void store_16bit_lo(T* dst, const float (&a)[8], bool
 }
 
 // v: accumulators of columns n + 4*h .. n + 4*h + 3 (h = 0, 1); hi_ok: the second half exists (n + 4 < N)
+// MODE 3: bias (+ GELU) then quantised to MX fp8 (the fp8 GEMM's fc1 epilogue, mx_fp8.h)
 // MODE: 0 = every option checked at run time; 1 / 2 = the ViT fast paths of EPI_STORE (16-bit output
 // only, bias, no residual, no border; 1: no activation (qkv), 2: GELU (fc1)) with the branches gone
 template <typename T, int EPI, int MODE>
@@ -262,14 +264,17 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
         for (int h = 0; h < 2; ++h) {
             const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
-            if constexpr (MODE == 2) {
+            if constexpr (MODE == 2 || MODE == 3) {
                 const f32x4 g = gelu_erf4(f32x4{x0, x1, x2, x3});
                 a[4 * h] = g[0], a[4 * h + 1] = g[1], a[4 * h + 2] = g[2], a[4 * h + 3] = g[3];
             } else {
                 a[4 * h] = x0, a[4 * h + 1] = x1, a[4 * h + 2] = x2, a[4 * h + 3] = x3;
             }
         }
-        store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
+        if constexpr (MODE == 3)
+            store_granule_fp8(p, m, n, a);
+        else
+            store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
     } else if constexpr (EPI == EPI_STORE) {
         const int64_t row32 = (int64_t)m * p.ldc;
 #pragma unroll
@@ -372,7 +377,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
 // after_loads(): called once the per-lane constant loads have been issued (the tile queue draws its
 // ticket there, beside them)
 template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool PIN_CONSTS = false,
-          typename Hook = NoHook>
+          typename Hook = NoHook, int OUT8 = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
                                               int wm, int wn, int lane, char* epi_lds,
                                               Hook after_loads = Hook()) {
@@ -499,7 +504,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                          : "+v"(lc.gamma[0].x), "+v"(lc.gamma[0].y), "+v"(lc.gamma[0].z), "+v"(lc.gamma[0].w),
                            "+v"(lc.gamma[1].x), "+v"(lc.gamma[1].y), "+v"(lc.gamma[1].z), "+v"(lc.gamma[1].w));
         }
-        if constexpr (EPI == EPI_STORE) {
+        if constexpr (EPI == EPI_STORE && OUT8 != 0) {
+            run(std::integral_constant<int, 3>());  // bias + GELU -> MX fp8 (the only fp8-output user: fc1)
+        } else if constexpr (EPI == EPI_STORE) {
             const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias &&
                                 !p.lo_off16 && !p.ldc16;
             if (simple && p.act == ACT_NONE)

@@ -36,6 +36,10 @@ struct WeightSlot {
 struct VitBlockW {
     const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ls1, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls2;
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    // ME_DTYPE_FP8: MX fp8 copies of the three big linears (e4m3 bytes [N][K] + e8m0 block scales in the weight
+    // layout of mx_fp8.h), quantised on the device from the 16-bit arena when the weights are finalized
+    const uint8_t *qkv_w8 = nullptr, *qkv_ws = nullptr, *fc1_w8 = nullptr, *fc1_ws = nullptr, *fc2_w8 = nullptr,
+                  *fc2_ws = nullptr;
 };
 struct VitW {
     const void* patch_w;
@@ -96,6 +100,11 @@ struct DevBuf {
 struct me_ctx {
     int device = 0;
     int32_t dtype = ME_DTYPE_F16;
+    // ME_DTYPE_FP8 (BASELINE configs[3]): `dtype` is ME_DTYPE_F16 for every 16-bit operand, and the qkv / fc1 /
+    // fc2 linears of the three ViTs run on MX block-scaled fp8 (gemm_fp8.hip)
+    bool fp8 = false;
+    char* arena8 = nullptr;  // the fp8 weight copies (derived data: rebuilt after finalize / adopt / broadcast)
+    size_t arena8_bytes = 0;
     // Stages whose 16-bit activation operands are carried as hi + lo pairs (me::SplitStage bits)
     int32_t split_mask = 0;
     bool split(int stage_bit) const { return (split_mask & stage_bit) != 0; }
@@ -135,6 +144,8 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
                  const int64_t* dims, int32_t ndim);
 void finalize_weights(me_ctx* ctx);
 void load_checkpoint_pt(me_ctx* ctx, const char* path);
+// (re)derives the MX fp8 weight copies from the 16-bit arena (fp8 contexts; no-op otherwise)
+void build_fp8_weights(me_ctx* ctx);
 
 // persistent device buffer for a pipeline site; zero-filled when (re)allocated
 void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes);

@@ -1,0 +1,53 @@
+// MX block-scaled fp8 (OCP e4m3 elements, one e8m0 scale per 32 K elements): scale layouts and conversions
+// shared by the fp8 GEMM (gemm_fp8.hip) and the epilogues that produce its operands (gemm_core.h).
+#pragma once
+#include "common.h"
+
+namespace me {
+
+// ---- scale layouts (bytes) ------------------------------------------------------------------------------
+// activation operand, rows m (padded to 128-row wave tiles, `mt` of them), K block kb:
+__host__ __device__ __forceinline__ int64_t a_scale_index(int64_t m, int kb, int64_t mt) {
+    return (((int64_t)(kb >> 2) * mt + (m >> 7)) * 64 + (kb & 3) * 16 + (m & 15)) * 8 + ((m & 127) >> 4);
+}
+// weight operand, rows n (N a multiple of 64, `nt` = N / 64 wave tiles), K block kb:
+__host__ __device__ __forceinline__ int64_t w_scale_index(int64_t n, int kb, int64_t nt) {
+    return (((int64_t)(kb >> 2) * nt + (n >> 6)) * 64 + (kb & 3) * 16 + (n & 15)) * 4 + ((n & 63) >> 4);
+}
+
+// e8m0 scale of a block with largest magnitude amax: the element grid is e4m3 (largest normal 448 = 1.75 * 2^8),
+// so the block exponent is floor(log2 amax) - 8, one more when amax's significand is >= 1.75 -- then no scaled
+// element exceeds 448 and the conversion needs no saturation.  amax = 0 gives byte 0 (2^-127): elements are 0.
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const unsigned e = ((__float_as_uint(amax) & 0x7fffffffu) + 0x200000u) >> 23;
+    return e > 8u ? (e - 8u > 254u ? 254u : e - 8u) : 0u;
+}
+// 1 / 2^(byte - 127) as a float (byte in [0, 254]); 2^127 needs the two-step form
+__device__ __forceinline__ float mx_inv_scale(unsigned byte) {
+    return byte == 0 ? 1.7014118e38f : __uint_as_float((254u - byte) << 23);
+}
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+// the fp8 + scales form of an epilogue granule (fc1: bias + GELU, then quantised as the next GEMM's activation
+// operand): 8 consecutive columns of one row per lane, 4 adjacent lanes share a 32-column MX block
+__device__ __forceinline__ void store_granule_fp8(const GemmParams& p, int m, int n, const float (&a)[8]) {
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(a[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const unsigned sb = mx_scale_byte(amax);
+    const float inv = mx_inv_scale(sb);
+    uint2 v;
+    v.x = pack_fp8x4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+    v.y = pack_fp8x4(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
+    *reinterpret_cast<uint2*>(p.out8 + (int64_t)m * p.ldc + n) = v;
+    if ((n & 31) == 0) p.out8_scale[a_scale_index(m, n >> 5, p.out8_mt)] = (uint8_t)sb;
+}
+
+}  // namespace me

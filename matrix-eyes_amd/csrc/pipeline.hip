@@ -266,6 +266,8 @@ struct MergedVit {
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
     float* fin32 = nullptr;
+    // ME_DTYPE_FP8: xn and hid hold e4m3 bytes, with their block scales (activation layout, Rtot / 128 tiles)
+    uint8_t *xn_s = nullptr, *hid_s = nullptr;
     RowSegs segs;
 
     static int64_t pad256(int64_t r) { return (r + 255) / 256 * 256; }
@@ -285,13 +287,27 @@ struct MergedVit {
         qkv = (char*)site_buf(ctx, "vitm.qkv", (size_t)Rtot * 3 * C * 2);
         att = (char*)site_buf(ctx, "vitm.att", (size_t)Rtot * C * 2);
         hid = (char*)site_buf(ctx, "vitm.hid", (size_t)Rtot * 4 * C * 2);
+        if (ctx->fp8) {
+            xn_s = (uint8_t*)site_buf(ctx, "vitm.xn.scale", (size_t)Rtot * C / 32);
+            hid_s = (uint8_t*)site_buf(ctx, "vitm.hid.scale", (size_t)Rtot * 4 * C / 32);
+        }
         fin16 = (char*)site_buf(ctx, "vitm.final16", (size_t)Rtot * C * 2);
         segs.seg1 = seg1, segs.seg2 = seg2, segs.win0 = W0, segs.win1 = W1;
         // vit.rs:287-295 per ViT: patch embed + cls + pos into its segment
         embed(v0, patches_main, W0, 0);
         embed(v1, patches_img, W1, seg1);
         if (fov) embed(v2, patches_fov, W1, seg2);
+        // The padding rows of each segment take part in every row-wise kernel of a block (x += gamma * (...),
+        // 48 times per call) and the buffer outlives the call: zeroed here, they hold the same finite values on
+        // every call instead of growing without bound or keeping another batch size's rows.
+        zero_rows(R0, seg1);
+        zero_rows(seg1 + (int64_t)W1 * T, seg1 + side);
+        if (fov) zero_rows(seg2 + (int64_t)W1 * T, Rtot);
         (void)P;
+    }
+
+    void zero_rows(int64_t r0, int64_t r1) {
+        if (r1 > r0) ME_HIP(hipMemsetAsync(tok + r0 * ctx->C(), 0, (size_t)(r1 - r0) * ctx->C() * 4, s));
     }
 
     void embed(const VitW& v, const void* patches16, int W, int64_t row) {
@@ -332,10 +348,49 @@ struct MergedVit {
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, C >= 256 && K >= 128 ? 0 : -1);
     }
 
+    // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales
+    void gemm8(const void* A8, const uint8_t* As, int K, int N, const VitBlockW& b0, const VitBlockW& b1,
+               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2*/) {
+        GemmParams p = base_params();
+        auto w8 = [&](const VitBlockW& b) { return which == 0 ? b.qkv_w8 : (which == 1 ? b.fc1_w8 : b.fc2_w8); };
+        auto ws = [&](const VitBlockW& b) { return which == 0 ? b.qkv_ws : (which == 1 ? b.fc1_ws : b.fc2_ws); };
+        auto bias = [&](const VitBlockW& b) { return which == 0 ? b.qkv_b : (which == 1 ? b.fc1_b : b.fc2_b); };
+        p.M = (int)Rtot, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = As, p.a_mt = (int)(Rtot / 128);
+        p.W = w8(b0), p.w_scale = ws(b0), p.bias = bias(b0), p.ldc = N;
+        p.seg1 = (int)seg1, p.seg2 = (int)seg2;
+        p.W_s1 = w8(b1), p.w_scale_s1 = ws(b1), p.bias_s1 = bias(b1);
+        p.W_s2 = w8(b2), p.w_scale_s2 = ws(b2), p.bias_s2 = bias(b2);
+        if (which == 0) {
+            p.out16 = qkv;
+            gemm_fp8_launch(p, EPI_STORE, s);
+        } else if (which == 1) {
+            p.act = ACT_GELU, p.out8 = (uint8_t*)hid, p.out8_scale = hid_s, p.out8_mt = (int)(Rtot / 128);
+            gemm_fp8_launch(p, EPI_STORE, s);
+        } else {
+            p.gamma = b0.ls2, p.gamma_s1 = b1.ls2, p.gamma_s2 = b2.ls2, p.res32 = tok, p.out32 = tok;
+            gemm_fp8_launch(p, EPI_RESID_SCALE, s);
+        }
+    }
+
     // vit.rs:163-170 Block::forward for the three ViTs
     void block(int i) {
         const VitBlockW &b0 = v0.blocks[i], &b1 = v1.blocks[i], &b2 = v2.blocks[i];
         const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
+        if (ctx->fp8) {
+            // BASELINE configs[3]: LayerNorm writes MX fp8, qkv / fc1 / fc2 run on the scaled fp8 MFMA; attention
+            // and its projection stay f16 (the attention kernel's operands and output are 16-bit)
+            set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
+            layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+            gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
+            attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
+            resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
+            set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
+            layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+            gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1);
+            gemm8(hid, hid_s, 4 * C, C, b0, b1, b2, 2);
+            if (taps.fn) taps.fn(taps.user, i, tok);
+            return;
+        }
         set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
         layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
         gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE);

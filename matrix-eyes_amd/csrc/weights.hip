@@ -393,6 +393,43 @@ void load_checkpoint_pt(me_ctx* ctx, const char* path) {
     finalize_weights(ctx);
 }
 
+// ME_DTYPE_FP8: quantise qkv / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
+// to MX fp8 on the device.  Derived data: a rank that received the arena by broadcast rebuilds it itself.
+void build_fp8_weights(me_ctx* ctx) {
+    if (!ctx->fp8) return;
+    const int64_t C = ctx->C();
+    struct Item {
+        const void* src;
+        int64_t N, K;
+        const uint8_t **w8, **ws;
+    };
+    std::vector<Item> items;
+    for (int v = 0; v < 3; ++v)
+        for (VitBlockW& b : ctx->w.vit[v].blocks) {
+            items.push_back({b.qkv_w, 3 * C, C, &b.qkv_w8, &b.qkv_ws});
+            items.push_back({b.fc1_w, 4 * C, C, &b.fc1_w8, &b.fc1_ws});
+            items.push_back({b.fc2_w, C, 4 * C, &b.fc2_w8, &b.fc2_ws});
+        }
+    size_t total = 0;
+    for (const Item& it : items) total += align_up((size_t)it.N * it.K, 256) + align_up((size_t)it.N * it.K / 32, 256);
+    if (!ctx->arena8 || ctx->arena8_bytes != total) {
+        if (ctx->arena8) ME_HIP(hipFree(ctx->arena8));
+        ctx->arena8 = nullptr;
+        ME_HIP(hipMalloc((void**)&ctx->arena8, total));
+        ctx->arena8_bytes = total;
+    }
+    size_t off = 0;
+    for (const Item& it : items) {
+        uint8_t* w8 = (uint8_t*)ctx->arena8 + off;
+        off += align_up((size_t)it.N * it.K, 256);
+        uint8_t* ws = (uint8_t*)ctx->arena8 + off;
+        off += align_up((size_t)it.N * it.K / 32, 256);
+        quantize_f16_to_fp8_launch(it.src, w8, ws, it.N, (int32_t)it.K, 1, ctx->stream);
+        *it.w8 = w8, *it.ws = ws;
+    }
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+}
+
 void finalize_weights(me_ctx* ctx) {
     std::string missing;
     int n = 0;
@@ -404,6 +441,7 @@ void finalize_weights(me_ctx* ctx) {
     // LoaderError::RecorderMissing (mod.rs:241-243)
     ME_CHECK(n == 0, ME_ERR_MISSING_WEIGHT, "%d tensors missing from the checkpoint: %s%s", n,
              missing.c_str(), n > 8 ? ", ..." : "");
+    build_fp8_weights(ctx);
     ctx->finalized = true;
 }
 

@@ -54,7 +54,7 @@ class Context:
         self.dtype = dtype
         self._h = C.c_void_p()
         ccfg = self.cfg.to_c()
-        code = {"f16": L.ME_DTYPE_F16, "bf16": L.ME_DTYPE_BF16}[dtype]
+        code = {"f16": L.ME_DTYPE_F16, "bf16": L.ME_DTYPE_BF16, "fp8": L.ME_DTYPE_FP8}[dtype]
         rc = self.lib.me_ctx_create(device_id, code, C.byref(ccfg), C.byref(self._h))
         if rc != L.ME_OK:
             raise L.MatrixEyesError(rc, self.lib.me_last_error(None).decode())

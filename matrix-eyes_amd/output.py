@@ -149,3 +149,48 @@ class DepthMap:
             self.ctx.handle, C.c_void_p(self.data.ctypes.data), self.data_width, self.data_height,
             self.original_width, self.original_height, destination_path.encode(), source_path.encode(),
             int(vertex_mode), C.c_void_p(colors.ctypes.data) if colors is not None else None))
+
+
+class DeviceDepthMap:
+    """DepthMap::new -> output_image chained on the GPU (BASELINE configs[4]: depth -> stereogram / depth map
+    without the host round trips of the reference's readback, output.rs:44-67).  `inverse_depth` is a CUDA f32
+    tensor [rows, cols] (e.g. the `out=` tensor of Context.extract_depth); it is clamped IN PLACE on the context's
+    stream and its range stays in device memory for the raster kernels queued behind it."""
+
+    def __init__(self, ctx: Context, inverse_depth, original_size):
+        import torch
+        if not (inverse_depth.is_cuda and inverse_depth.dtype == torch.float32 and inverse_depth.dim() == 2
+                and inverse_depth.is_contiguous()):
+            raise L.MatrixEyesError(2, "DeviceDepthMap: a contiguous CUDA f32 [rows, cols] tensor is required")
+        self.ctx, self.data = ctx, inverse_depth
+        self.data_width, self.data_height = inverse_depth.shape
+        self.original_width, self.original_height = original_size
+        self.range_dev = torch.empty(2, dtype=torch.float32, device=inverse_depth.device)
+        ctx._check(ctx.lib.me_depth_clamp_minmax_async(ctx.handle, C.c_void_p(inverse_depth.data_ptr()),
+                                                       inverse_depth.numel(), C.c_void_p(self.range_dev.data_ptr())))
+
+    def inverse_depth_range(self):
+        self.ctx.synchronize()
+        mn, mx = self.range_dev.tolist()
+        return mn, mx
+
+    def depth_map_rgb(self, out=None):
+        import torch
+        if out is None:
+            out = torch.empty(self.data.shape + (3,), dtype=torch.uint8, device=self.data.device)
+        self.ctx._check(self.ctx.lib.me_depthmap_rgb_dev_range(
+            self.ctx.handle, C.c_void_p(self.data.data_ptr()), self.data.numel(), C.c_void_p(self.range_dev.data_ptr()),
+            C.c_void_p(out.data_ptr())))
+        return out
+
+    def stereogram(self, amplitude: float, noise, out=None):
+        """noise: CUDA u8 [out_h, out_w, 3]"""
+        import torch
+        h, w = noise.shape[0], noise.shape[1]
+        if out is None:
+            out = torch.empty((h, w, 3), dtype=torch.uint8, device=self.data.device)
+        self.ctx._check(self.ctx.lib.me_stereogram_dev_range(
+            self.ctx.handle, C.c_void_p(self.data.data_ptr()), self.data_width, self.data_height,
+            C.c_void_p(self.range_dev.data_ptr()), w, h, amplitude, C.c_void_p(noise.data_ptr()),
+            C.c_void_p(out.data_ptr())))
+        return out

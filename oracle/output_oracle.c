@@ -218,3 +218,97 @@ void oracle_mesh_vertices(const float* depth, int32_t data_width, int32_t data_h
         xyz[3 * (int64_t)id + 2] = z_norm;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * output.rs:484-630 ObjWriter as a file writer, for OBJ files too large for the Python formatter
+ * (a 1536^2 textured mesh is ~450 MB).  Rust's `{}` for f64 prints the shortest decimal that
+ * round-trips, never in scientific notation.  Restated independently of the product's
+ * std::to_chars: the correctly rounded 15-, 16- or 17-significant-digit decimal (printf %.*e) --
+ * the first that strtod reads back to the same double is the shortest one, and being correctly
+ * rounded it is also the closest of that length, which is the digit string Rust's Grisu / Ryu
+ * prints -- then laid out positionally.
+ * ------------------------------------------------------------------------------------------- */
+#include <stdio.h>
+
+static int rust_display_f64(double v, char* out) { /* returns the length; out needs 400 bytes */
+    if (v != v) return sprintf(out, "NaN");
+    if (isinf(v)) return sprintf(out, v > 0 ? "inf" : "-inf");
+    if (v == 0.0) return sprintf(out, signbit(v) ? "-0" : "0");
+    char e[40];
+    int prec;
+    /* a normal double is identified by any decimal of <= 15 significant digits (DBL_DIG), so 15 digits either
+     * round-trip -- then trailing zeros are all that separates them from the shortest form -- or 16 or 17 are
+     * needed; subnormals have fewer bits and are searched from one digit up */
+    for (prec = fabs(v) < 2.2250738585072014e-308 ? 0 : 14; prec <= 16; ++prec) { /* %.14e = 15 digits */
+        snprintf(e, sizeof e, "%.*e", prec, v);
+        if (strtod(e, NULL) == v) break;
+    }
+    /* e = [-]d.ddddde[+-]xx : digits and decimal exponent */
+    char digits[24];
+    int nd = 0, neg = e[0] == '-';
+    const char* p = e + neg;
+    for (; *p && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    const int exp10 = atoi(p + 1);
+    while (nd > 1 && digits[nd - 1] == '0') --nd; /* shortest: trailing zeros carry nothing */
+    int n = 0;
+    if (neg) out[n++] = '-';
+    if (exp10 >= 0) {
+        for (int i = 0; i <= exp10; ++i) out[n++] = i < nd ? digits[i] : '0';
+        if (nd > exp10 + 1) {
+            out[n++] = '.';
+            for (int i = exp10 + 1; i < nd; ++i) out[n++] = digits[i];
+        }
+    } else {
+        out[n++] = '0';
+        out[n++] = '.';
+        for (int i = 0; i < -exp10 - 1; ++i) out[n++] = '0';
+        for (int i = 0; i < nd; ++i) out[n++] = digits[i];
+    }
+    out[n] = 0;
+    return n;
+}
+
+/* test hook for the formatter above */
+int oracle_rust_display_f64(double v, char* out) { return rust_display_f64(v, out); }
+
+/* vertex_mode: 0 plain, 1 vertex colours, 2 texture coordinates (output.rs:34-38).  uv [nverts][2], xyz
+ * [nverts][3] as oracle_mesh_vertices returns them, faces [nfaces][3] 0-based, colors [nverts][3] or NULL.
+ * Returns 0, or -1 when the file cannot be written. */
+int oracle_write_obj(const char* path, const char* stem, int32_t vertex_mode, const float* uv, const float* xyz,
+                     int64_t nverts, const int32_t* faces, int64_t nfaces, const uint8_t* colors) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    static char buf[1 << 16];
+    setvbuf(f, buf, _IOFBF, sizeof buf);
+    char a[400], b[400], c[400];
+    if (vertex_mode == 2) { /* :551-564 header, :592-602 write_vertex_texture */
+        fprintf(f, "mtllib %s.mtl\nusemtl Textured\n", stem);
+        for (int64_t i = 0; i < nverts; ++i) {
+            rust_display_f64((double)uv[2 * i], a);
+            rust_display_f64(1.0 - (double)uv[2 * i + 1], b);
+            fprintf(f, "vt %s %s\n", a, b);
+        }
+    }
+    for (int64_t i = 0; i < nverts; ++i) { /* :566-590 write_vertex: x, -y, -z (negated in f32, :235-249) */
+        rust_display_f64((double)xyz[3 * i], a);
+        rust_display_f64((double)(-xyz[3 * i + 1]), b);
+        rust_display_f64((double)(-xyz[3 * i + 2]), c);
+        fprintf(f, "v %s %s %s", a, b, c);
+        if (vertex_mode == 1 && colors) {
+            for (int k = 0; k < 3; ++k) {
+                rust_display_f64((double)colors[3 * i + k] / 255.0, a);
+                fprintf(f, " %s", a);
+            }
+        }
+        fputc('\n', f);
+    }
+    for (int64_t i = 0; i < nfaces; ++i) { /* :604-620 write_face, 1-based */
+        const long long x = faces[3 * i] + 1ll, y = faces[3 * i + 1] + 1ll, z = faces[3 * i + 2] + 1ll;
+        if (vertex_mode == 2)
+            fprintf(f, "f %lld/%lld %lld/%lld %lld/%lld\n", x, x, y, y, z, z);
+        else
+            fprintf(f, "f %lld %lld %lld\n", x, y, z);
+    }
+    return fclose(f) == 0 ? 0 : -1;
+}

@@ -113,6 +113,28 @@ def obj_text(uv, xyz, faces, vertex_mode: str, stem: str, colors=None) -> str:
     return "".join(out)
 
 
+def rust_display_f64_c(v: float) -> str:
+    """the C restatement of Rust's `{}` for f64 (output_oracle.c), used by write_obj"""
+    buf = C.create_string_buffer(400)
+    lib().oracle_rust_display_f64(C.c_double(v), buf)
+    return buf.value.decode()
+
+
+def write_obj(path, uv, xyz, faces, vertex_mode: str, stem: str, colors=None):
+    """output.rs:484-630 ObjWriter straight to a file (C): for meshes too large for obj_text"""
+    mode = {"plain": 0, "color": 1, "texture": 2}[vertex_mode]
+    uv = np.ascontiguousarray(uv, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    col = None if colors is None else np.ascontiguousarray(colors, np.uint8)
+    fn = lib().oracle_write_obj
+    fn.restype = C.c_int
+    rc = fn(os.fsencode(path), stem.encode(), C.c_int32(mode), _p(uv), _p(xyz), C.c_int64(len(xyz)), _p(faces),
+            C.c_int64(len(faces)), _p(col) if col is not None else C.c_void_p(0))
+    if rc != 0:
+        raise OSError(f"cannot write {path}")
+
+
 def mtl_text(image_path: str) -> str:
     """output.rs:536-544"""
     return ("newmtl Textured\nKa 0.2 0.2 0.2\nKd 0.8 0.8 0.8\nKs 1.0 1.0 1.0\nillum 2\nNs 0.000500\n"

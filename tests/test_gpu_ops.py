@@ -358,3 +358,130 @@ def test_conv_transpose(dtype, cfg):
     assert max_abs_rel(out32.cpu(), ref) < 2e-5
     assert max_abs_rel(out16[:, 1:-1, 1:-1, :].float().cpu(), ref) < 6 * OUT_EPS[dtype] * 4
     assert float(out16[:, 0].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
+
+
+def _vit_block_gpu(ctx, x32, w, i, C, T, windows, heads, dtype):
+    """One Block::forward (vit.rs:163-170) from the kernel-level entry points, in place on x32 [rows, C]"""
+    rows = x32.shape[0]
+    t16 = TORCH16[dtype]
+    xn = torch.empty(rows, C, dtype=t16, device="cuda")
+    qkv = torch.empty(rows, 3 * C, dtype=t16, device="cuda")
+    att = torch.empty(rows, C, dtype=t16, device="cuda")
+    hid = torch.empty(rows, 4 * C, dtype=t16, device="cuda")
+    p = f"encoder.patch_encoder.blocks.{i}."
+    d = {k: torch.as_tensor(w[p + k]).cuda() for k in
+         ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+          "ls1.gamma", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias",
+          "ls2.gamma")}
+    f = {k: v.float().contiguous() for k, v in d.items()}
+    h = {k: v.to(t16).contiguous() for k, v in d.items() if k.endswith("weight") and v.dim() == 2}
+    L = ctx.lib
+    _check(ctx, L.me_op_layernorm(ctx.handle, ptr(x32), ptr(f["norm1.weight"]), ptr(f["norm1.bias"]), ptr(xn), None, rows, C, 1e-5))
+    _check(ctx, L.me_op_linear(ctx.handle, rows, 3 * C, C, ptr(xn), ptr(h["attn.qkv.weight"]), ptr(f["attn.qkv.bias"]), ptr(qkv), None, 0, -1))
+    _check(ctx, L.me_op_attention(ctx.handle, ptr(qkv), ptr(att), windows, T, heads))
+    _check(ctx, L.me_op_linear_residual(ctx.handle, rows, C, C, ptr(att), ptr(h["attn.proj.weight"]), ptr(f["attn.proj.bias"]), ptr(f["ls1.gamma"]), ptr(x32), -1))
+    _check(ctx, L.me_op_layernorm(ctx.handle, ptr(x32), ptr(f["norm2.weight"]), ptr(f["norm2.bias"]), ptr(xn), None, rows, C, 1e-5))
+    _check(ctx, L.me_op_linear(ctx.handle, rows, 4 * C, C, ptr(xn), ptr(h["mlp.fc1.weight"]), ptr(f["mlp.fc1.bias"]), ptr(hid), None, 1, -1))
+    _check(ctx, L.me_op_linear_residual(ctx.handle, rows, C, 4 * C, ptr(hid), ptr(h["mlp.fc2.weight"]), ptr(f["mlp.fc2.bias"]), ptr(f["ls2.gamma"]), ptr(x32), -1))
+    ctx.synchronize()
+    return qkv, hid
+
+
+def test_outlier_activations_through_a_block():
+    """All other parity runs on N(0, 1/fan_in) weights; real DINOv2-L checkpoints carry massive activations in a
+    few channels of the residual stream.  What the f16 path does with them, one Block (vit.rs:163-170) on the
+    tiny geometry:
+      * outliers of 3e4 in the f32 residual stream (beyond anything LayerNorm lets through to a GEMM operand):
+        the block's output matches the fp64 oracle as closely as without them -- the stream, the LayerNorm
+        statistics and the residual adds are f32, and what reaches the 16-bit operands is normalised;
+      * 16-bit operands up to the f16 maximum are exact: a qkv pre-activation of 6.0e4 is stored as 6.0e4;
+      * past 65504 the 16-bit copy of a GEMM output is +-inf (round-to-nearest conversion, no saturation), the
+        attention / MLP that consume it go non-finite and so does the depth: the overflow is loud (bench.py and
+        the pipeline tests assert finiteness), never a silently clamped value.  ME_DTYPE_BF16 (f32's exponent
+        range) is the operand type for a checkpoint that needs that range: the same block stays finite there."""
+    import matrix_eyes_amd as m
+    from oracle import depth_pro_oracle as O
+    from util import oracle_cfg, weights_for
+    cfg = m.ModelConfig.tiny()
+    w = {k: torch.as_tensor(v) for k, v in weights_for("tiny").items()}
+    C, T, heads, windows = cfg.embed_dim, cfg.tokens, cfg.num_heads, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(windows, T, C, generator=g)
+    spiky = x.clone()
+    spiky[:, 0, 7] = 3.0e4          # a massive activation in the cls token of every window
+    spiky[:, 5, 100] = -2.0e4
+    ocfg = oracle_cfg(cfg, dtype=torch.float64)
+    w64 = {k: v.double() for k, v in w.items()}
+    ctx = ctx_for("tiny", "f16")
+    for name, inp in (("plain", x), ("spiky", spiky)):
+        ref = O.block_forward(inp.double(), w64, "encoder.patch_encoder.blocks.0.", ocfg)
+        got = inp.reshape(-1, C).contiguous().cuda()
+        _vit_block_gpu(ctx, got, w, 0, C, T, windows, heads, "f16")
+        delta_ref = ref.reshape(-1, C) - inp.reshape(-1, C).double()       # what the block adds
+        delta_got = got.cpu().double() - inp.reshape(-1, C).double()
+        err = float((delta_got - delta_ref).norm() / delta_ref.norm())
+        print("block update rel-L2", name, err)
+        assert torch.isfinite(got).all() and err < 1.5e-3
+    # operands at and past the f16 maximum: qkv weights scaled so that one pre-activation column reaches 6.0e4 / 7e4
+    big = dict(w)
+    for target, finite in ((6.0e4, True), (7.0e4, False)):
+        wq = w["encoder.patch_encoder.blocks.0.attn.qkv.weight"].float().clone()
+        bq = w["encoder.patch_encoder.blocks.0.attn.qkv.bias"].float().clone()
+        wq[2 * C + 3] = 0.0
+        bq[2 * C + 3] = target      # a value column (v of head 0, dim 3) pinned to `target`
+        big["encoder.patch_encoder.blocks.0.attn.qkv.weight"] = wq.half()
+        big["encoder.patch_encoder.blocks.0.attn.qkv.bias"] = bq
+        got = x.reshape(-1, C).contiguous().cuda()
+        qkv, _ = _vit_block_gpu(ctx, got, big, 0, C, T, windows, heads, "f16")
+        col = qkv[:, 2 * C + 3].float()
+        if finite:
+            assert torch.equal(col, torch.full_like(col, float(torch.tensor(target).half()))) and torch.isfinite(got).all()
+        else:
+            assert torch.isinf(col).all() and not torch.isfinite(got).all()
+            bctx = ctx_for("tiny", "bf16")
+            gotb = x.reshape(-1, C).contiguous().cuda()
+            _vit_block_gpu(bctx, gotb, big, 0, C, T, windows, heads, "bf16")
+            assert torch.isfinite(gotb).all()
+
+
+def test_outlier_activations_through_a_residual_conv_unit():
+    """decoder.rs:35-44 ResidualConvUnit with inputs of 1e4 (maxima near 4.5e4): x + conv2(relu(conv1(relu(x)))) keeps
+    x in f32, the 16-bit operands are relu(x) <= 65504 and the first conv's output stays below the f16 maximum by
+    construction of the weights here, so the unit is as accurate as at unit scale.  Scaled 30x further the 16-bit
+    operand overflows to +inf, the first conv sums infinities of both signs to NaN -- and the ReLU behind it maps
+    NaN to 0 (fmaxf, exactly what f32::max does in the reference's relu): the branch silently drops out and the
+    unit returns x + bias terms, finite.  So on the conv stages an f16 overflow is NOT loud; the operand type for
+    a checkpoint with such magnitudes is ME_DTYPE_BF16.  (The fp32 reference has no such limit: this is a property
+    of 16-bit operands, stated here so that it is known, with the magnitudes at which it starts.)"""
+    ctx = ctx_for("tiny", "f16")
+    B, H, Cc = 1, 24, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Cc, H, H, generator=g)
+    w1 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    b1, b2 = torch.randn(Cc, generator=g) * 0.02, torch.randn(Cc, generator=g) * 0.02
+    for scale, finite in ((1.0, True), (1.0e4, True), (3.0e5, False)):
+        xs = x * scale
+        x32 = xs.permute(0, 2, 3, 1).reshape(-1, Cc).contiguous().cuda()
+        a16 = bordered(torch.relu(xs), "f16")
+        t16 = torch.zeros(B, H + 2, H + 2, Cc, dtype=torch.float16, device="cuda")
+        out32 = torch.empty(B * H * H, Cc, dtype=torch.float32, device="cuda")
+        wa, wb = dev16(pack_conv(w1), "f16"), dev16(pack_conv(w2), "f16")
+        b1d, b2d = b1.cuda(), b2.cuda()
+        _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(a16), B, H, H, Cc, ptr(wa), Cc, 3, 1, ptr(b1d), None, None,
+                                         None, ptr(t16), 1, 2, 0, -1))
+        _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(t16), B, H, H, Cc, ptr(wb), Cc, 3, 1, ptr(b2d), ptr(x32), None,
+                                         ptr(out32), None, 0, 0, 0, -1))
+        ctx.synchronize()
+        if not finite:
+            assert torch.isinf(a16).any() and torch.isfinite(out32).all()
+            assert not torch.isinf(t16).any() and float(t16.float().abs().max()) == 0.0      # NaN -> relu -> 0
+            continue
+        wa64, wb64 = w1.half().double(), w2.half().double()
+        ref = xs.double() + F.conv2d(torch.relu(F.conv2d(torch.relu(xs.half().double()), wa64, b1.double(), padding=1)),
+                                     wb64, b2.double(), padding=1)
+        branch = ref - xs.double()
+        got = out32.cpu().double().reshape(B, H, H, Cc).permute(0, 3, 1, 2)
+        err = float(((got - xs.double()) - branch).norm() / branch.norm())
+        print("RCU branch rel-L2 at scale", scale, err)
+        assert torch.isfinite(out32).all() and err < 1.0e-3

@@ -218,3 +218,41 @@ def test_bad_destination_is_an_error(tmp_path):
     rc = ctx.lib.me_output_mesh(ctx.handle, C.c_void_p(d.ctypes.data), 16, 16, 16, 16,
                                 b"/nonexistent-dir/x.obj", b"src", 0, None)
     assert rc == 7      # OutputError::Io
+
+
+def test_config4_chain_full_size(tmp_path):
+    """BASELINE configs[4] for one image at full size: model -> DepthMap -> stereogram -> textured OBJ.  The depth
+    stays on the GPU from the model's output tensor through DepthMap::new (clamp + range, output.rs:44-75) into the
+    stereogram kernel (no host round trip); given that depth, the stereogram is bit-exact against the C oracle and
+    the 450 MB OBJ + MTL are byte-identical to the oracle's writer (output.rs:484-630)."""
+    import filecmp
+    import torch
+    from matrix_eyes_amd.synthetic import synthetic_images
+    from util import loaded_ctx
+    ctx = loaded_ctx("full", "f16")
+    S = ctx.cfg.img_size
+    rgb = torch.from_numpy(synthetic_images(1, S, "structured", seed=31)).cuda()
+    depth = torch.empty(1, S, S, dtype=torch.float32, device="cuda")
+    ctx.extract_depth(rgb, None, out=depth)
+    raw = depth[0].cpu().numpy().copy()                     # before DepthMap::new clamps it in place
+    ddm = m.DeviceDepthMap(ctx, depth[0], (S, S))
+    noise = np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)
+    stereo = ddm.stereogram(1.0 / 16.0, torch.from_numpy(noise).cuda())
+    colour = ddm.depth_map_rgb()
+    od, mn, mx = OO.clamp_minmax(raw)
+    assert ddm.inverse_depth_range() == (mn, mx) and np.array_equal(depth[0].cpu().numpy(), od)
+    assert np.array_equal(stereo.cpu().numpy(), OO.stereogram(od, mn, mx, S, S, 1.0 / 16.0, noise))
+    assert np.array_equal(colour.cpu().numpy(), OO.depthmap_rgb(od, mn, mx))
+    # the host-side DepthMap of the same depth agrees with the device chain
+    dm = m.DepthMap(ctx, raw, (S, S))
+    assert dm.inverse_depth_range() == (mn, mx) and np.array_equal(dm.data, od)
+    # output.rs:195-261: textured OBJ + MTL, whole file against the oracle's writer
+    dest = tmp_path / "mesh.obj"
+    dm.output_image(str(dest), "photo.jpg", m.ImageOutputFormat.DepthMap(), m.VertexMode.Texture)
+    vi, nv, faces = OO.mesh_index(od)
+    uv, xyz = OO.mesh_vertices(od, vi, nv, (S, S))
+    assert nv > 0.5 * S * S and len(faces) > S * S          # a real mesh, not the degenerate case
+    OO.write_obj(str(tmp_path / "oracle.obj"), uv, xyz, faces, "texture", "mesh")
+    assert dest.stat().st_size == (tmp_path / "oracle.obj").stat().st_size > 100e6
+    assert filecmp.cmp(dest, tmp_path / "oracle.obj", shallow=False)
+    assert (tmp_path / "mesh.mtl").read_text() == OO.mtl_text("photo.jpg")

@@ -120,6 +120,76 @@ def test_device_pointers_and_determinism():
     assert np.array_equal(out1.cpu().numpy(), host)
 
 
+def test_state_dict_with_extra_keys_loads_like_the_reference(tmp_path):
+    """mod.rs:236-243 checks `result.errors` and `result.missing` only: keys the model does not use (wrapper
+    siblings, EMA copies, integer buffers, bf16 tensors) are normal.  Both loaders skip and list them; the depth
+    equals the plain checkpoint's."""
+    cfg = m.ModelConfig.tiny()
+    w = dict(weights_for("tiny"))
+    extra = {"ema.decay": torch.tensor(0.999, dtype=torch.float64), "step": torch.tensor([7], dtype=torch.int64),
+             "aux.proj.weight": torch.randn(4, 4, dtype=torch.bfloat16)}
+    rgb = synthetic_images(1, cfg.img_size)
+    want = loaded_ctx("tiny", "f16").extract_depth(rgb, 1.0)
+    ctx = m.Context(0, "f16", cfg)
+    ctx.load_state_dict({**extra, **w})
+    assert sorted(ctx.unused_keys) == sorted(extra) and np.array_equal(ctx.extract_depth(rgb, 1.0), want)
+    ctx.close()
+    # the library's own reader (me_load_checkpoint_pt), a {"state_dict": ...} wrapper with siblings
+    ck = {k: torch.as_tensor(v) for k, v in w.items()}
+    torch.save({"state_dict": {**ck, **extra}, "epoch": 3}, tmp_path / "wrapped.pt")
+    ctx = m.Context(0, "f16", cfg)
+    ctx.load_checkpoint_pt(str(tmp_path / "wrapped.pt"))
+    assert sorted(ctx.unused_keys) == sorted(extra) and np.array_equal(ctx.extract_depth(rgb, 1.0), want)
+    ctx.close()
+    # bf16 / f64 storage of a tensor the model does use is converted, a wrong shape stays an error
+    ck2 = dict(ck)
+    name = "head.4.bias"
+    ck2[name] = ck[name].to(torch.float64)
+    torch.save(ck2, tmp_path / "f64.pt")
+    ctx = m.Context(0, "f16", cfg)
+    ctx.load_checkpoint_pt(str(tmp_path / "f64.pt"))
+    assert np.array_equal(ctx.extract_depth(rgb, 1.0), want)
+    ctx.close()
+    ck2[name] = torch.zeros(2)
+    torch.save(ck2, tmp_path / "shape.pt")
+    ctx = m.Context(0, "f16", cfg)
+    with pytest.raises(m.MatrixEyesError) as e:
+        ctx.load_checkpoint_pt(str(tmp_path / "shape.pt"))
+    assert e.value.code == 4
+    with pytest.raises(m.MatrixEyesError) as e:
+        ctx.load_checkpoint_pt(str(tmp_path / "absent.pt"))
+    assert e.value.code == 7          # LoaderError::Pytorch
+    ctx.close()
+
+
+def test_padding_rows_stay_finite_across_batch_sizes():
+    """The three ViTs share one row space with each segment padded to 256 rows; the padding rows take part in
+    every row-wise kernel.  They are re-zeroed per call: a batch of 2, then of 1, then of 2 reproduces itself."""
+    ctx = loaded_ctx("tiny", "f16")
+    rgb = synthetic_images(2, ctx.cfg.img_size, seed=5)
+    first = [ctx.extract_depth(rgb, None, want_fov=True) for _ in range(1)][0]
+    for _ in range(3):
+        ctx.extract_depth(rgb[:1], None)
+        again = ctx.extract_depth(rgb, None, want_fov=True)
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+
+
+def test_bcast_weights_single_rank_runs_rccl():
+    """me_bcast_weights with one rank still creates a communicator, broadcasts the arena in place and destroys the
+    communicator: every RCCL call of the native start-up path executes on a one-GPU box."""
+    src = loaded_ctx("tiny", "f16")
+    rgb = synthetic_images(1, src.cfg.img_size)
+    want = src.extract_depth(rgb, 1.0)
+    before = src.weight_arena_tensor().clone()
+    src.bcast_weights(src.rccl_unique_id(), 0, 1)
+    assert torch.equal(src.weight_arena_tensor(), before) and np.array_equal(src.extract_depth(rgb, 1.0), want)
+    fresh = m.Context(0, "f16", src.cfg)
+    with pytest.raises(m.MatrixEyesError) as e:          # rank 0 must hold finalized weights
+        fresh.bcast_weights(fresh.rccl_unique_id(), 0, 1)
+    assert e.value.code == 8
+    fresh.close()
+
+
 def test_missing_and_unexpected_weights():
     cfg = m.ModelConfig.tiny()
     ctx = m.Context(0, "f16", cfg)
@@ -178,26 +248,89 @@ def test_progress_callback():
     assert abs(by_msg["forwarding head"] - 0.99) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", ["f16"])
-def test_extract_depth_full_size(dtype):
-    """BASELINE config 2: one 1536x1536 image through the full-size model (951.99 M synthetic
-    parameters), FOV head on, against the fp32 oracle (about 20 TFLOP of CPU work)."""
-    ctx = loaded_ctx("full", dtype)
-    cfg, w = ctx.cfg, weights_for("full")
-    assert cfg.img_size == m.IMG_SIZE == 1536
-    assert ctx.weight_arena_bytes() > 1.9e9
+@pytest.fixture(scope="module")
+def full_oracle():
+    """One 1536x1536 image through the fp32 oracle (about 20 TFLOP of CPU work), shared by the full-size tests"""
+    cfg, w = m.ModelConfig(), weights_for("full")
     img = _img(cfg)
-    got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
-    torch.set_num_threads(max(1, torch.get_num_threads()))
     ref, ref_fov = O.extract_depth(img, None, w, oracle_cfg(cfg))
-    rep = depth_error_report(got, ref.numpy())
-    print("full-size", dtype, rep, float(fov[0]), float(ref_fov[0]))
-    # north_star: depth within 1e-3 relative of the CPU reference.  Measured (deterministic): median per-pixel
-    # relative error 2.0e-4, relative L2 over the map 1.01e-3 -- about 23 sequential f16 operand roundings of
-    # 2.1e-4 each in quadrature (DESIGN.md section 5); the bounds leave a fifth of headroom over those figures
-    assert rep["median"] < 2.5e-4
-    assert rep["rel_l2"] < 1.2e-3
-    assert abs(float(fov[0]) - float(ref_fov[0])) < 0.1
+    return img, ref.numpy(), float(ref_fov[0])
+
+
+def test_extract_depth_full_size(full_oracle):
+    """BASELINE configs[1]: one 1536x1536 image through the full-size model (951.99 M synthetic parameters),
+    FOV head on, f16 operands, against the fp32 oracle.  north_star: depth within 1e-3 relative of the CPU
+    reference -- asserted as such.  Measured: relative L2 7.1e-4, median per-pixel relative error 1.4e-4 with the
+    default split-operand stages (me_model_config.split_operands = 3); 1.01e-3 / 2.0e-4 without them."""
+    ctx = loaded_ctx("full", "f16")
+    cfg = ctx.cfg
+    assert cfg.img_size == m.IMG_SIZE == 1536 and cfg.split_operands == 3
+    assert ctx.weight_arena_bytes() > 1.9e9
+    img, ref, ref_fov = full_oracle
+    got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
+    rep = depth_error_report(got, ref)
+    print("full-size f16", rep, float(fov[0]), ref_fov)
+    assert rep["rel_l2"] < 1.0e-3
+    assert rep["median"] < 2.0e-4
+    assert abs(float(fov[0]) - ref_fov) < 0.05
+
+
+def test_split_operand_stages_buy_the_margin(full_oracle):
+    """me_model_config.split_operands: the stages of the un-diluted conv chain carried as hi + lo operands.
+    Without them the same path sits on the 1e-3 bound (1.01e-3 measured); with every stage split it reaches
+    5.2e-4.  Each context is created, measured and destroyed (1.9 GB of weights each)."""
+    img, ref, _ = full_oracle
+    errs = {}
+    for mask in (0, 15):
+        cfg = m.ModelConfig(split_operands=mask)
+        ctx = m.Context(0, "f16", cfg)
+        ctx.load_state_dict(weights_for("full"))
+        errs[mask] = depth_error_report(ctx.extract_depth(img.numpy(), None), ref)["rel_l2"]
+        ctx.close()
+    print("split_operands 0 / 15: rel_l2", errs)
+    assert errs[15] < 6.5e-4 < errs[0] < 1.2e-3
+
+
+def test_extract_depth_full_size_bf16(full_oracle):
+    """BASELINE configs[1] names bf16: the same image with bf16 MFMA operands (weights rounded from the fp16
+    checkpoint to bf16, 8 significand bits).  Reported, not held to 1e-3: bf16 rounds every operand 8x coarser
+    than f16 at the same MFMA rate, which is why f16 is the default.  Tolerance: 1e-2 relative L2."""
+    ctx = loaded_ctx("full", "bf16")
+    img, ref, ref_fov = full_oracle
+    got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
+    rep = depth_error_report(got, ref)
+    print("full-size bf16", rep, float(fov[0]), ref_fov)
+    assert rep["rel_l2"] < 1.0e-2
+    assert abs(float(fov[0]) - ref_fov) < 0.5
+
+
+def test_extract_depth_full_size_fp8(full_oracle):
+    """BASELINE configs[3]: the full-size model with the qkv / fc1 / fc2 linears of the three ViTs on MX
+    block-scaled fp8 (e4m3 elements, one e8m0 scale per 32 K elements; 2x the 16-bit MFMA rate), everything else
+    f16.  fp8 operands carry 3 significand bits, so this configuration is NOT held to north_star's 1e-3: its depth
+    error against the fp32 oracle is reported here (and in DESIGN.md); the bound asserted is 5e-2 relative L2."""
+    ctx = loaded_ctx("full", "fp8")
+    img, ref, ref_fov = full_oracle
+    got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
+    rep = depth_error_report(got, ref)
+    print("full-size fp8", rep, float(fov[0]), ref_fov)
+    assert np.isfinite(got).all() and rep["rel_l2"] < 5.0e-2
+    assert abs(float(fov[0]) - ref_fov) < 2.0
+
+
+def test_full_size_batch_of_eight():
+    """BASELINE configs[2]: 8 images per GPU per step.  Images 2 and 7 of the batch are bit for bit what a batch
+    of one produces (280 + 8 + 8 windows in three row segments, other tile rounds than at batch 1), every depth
+    is finite and inside the clamp of mod.rs:362."""
+    ctx = loaded_ctx("full", "f16")
+    rgb = synthetic_images(8, ctx.cfg.img_size, "structured", seed=99)
+    batch, fovs = ctx.extract_depth(rgb, None, want_fov=True)
+    assert batch.shape == (8, 1536, 1536) and np.isfinite(batch).all() and np.isfinite(fovs).all()
+    assert batch.min() >= 1e-4 and batch.max() <= 1e4
+    for i in (2, 7):
+        one, fov1 = ctx.extract_depth(rgb[i:i + 1], None, want_fov=True)
+        assert np.array_equal(batch[i], one[0]) and fovs[i] == fov1[0]
+    assert len({batch[i].tobytes() for i in range(8)}) == 8
 
 
 def test_full_size_batch_equals_loop_of_batch_one():

@@ -114,3 +114,24 @@ def test_obj_and_ply_writers():
     assert b.startswith(b"ply\nformat binary_big_endian 1.0\ncomment Matrix Eyes 3D surface\nelement vertex 2\n")
     assert b.endswith(struct.pack(">BIII", 3, 0, 1, 1))
     assert len(b) == b.index(b"end_header\n") + 11 + 2 * 24 + 13
+
+
+def test_c_obj_writer_equals_python_formatter(tmp_path):
+    """The oracle holds the OBJ text twice: obj_text (Python, Decimal(repr(x)) for Rust's `{}` on f64) and
+    oracle_write_obj (C, printf-based shortest round-trip search) for full-size meshes.  They must agree on
+    numbers of every magnitude and on a whole file in each vertex mode."""
+    rng = np.random.default_rng(0)
+    vals = list(rng.standard_normal(4000).astype(np.float32).astype(np.float64)) + list(rng.random(4000))
+    vals += list(np.ldexp(rng.random(2000), rng.integers(-70, 70, 2000)))
+    vals += [0.0, -0.0, 1.0, -1.0, 0.1, 1e-7, 123456789.0, 1e21, 5e-324, 2.5e-310, 1.7976931348623157e308, 0.5, 100.0,
+             1 / 3, 0.30000000000000004, float(np.float32(0.1)), float(np.float32(1 / 255)), 250.0, float("inf"), float("nan")]
+    for v in vals:
+        assert OO.rust_display_f64_c(float(v)) == OO.rust_display_f64(float(v)), repr(v)
+    n = 24
+    d, _, _ = OO.clamp_minmax(np.abs(rng.standard_normal((n, n))).astype(np.float32) * 0.02 + 0.5)
+    vi, nv, faces = OO.mesh_index(d)
+    uv, xyz = OO.mesh_vertices(d, vi, nv, (n, n))
+    colors = rng.integers(0, 256, size=(nv, 3), dtype=np.uint8)
+    for mode in ("plain", "color", "texture"):
+        OO.write_obj(str(tmp_path / f"{mode}.obj"), uv, xyz, faces, mode, "mesh", colors if mode == "color" else None)
+        assert (tmp_path / f"{mode}.obj").read_text() == OO.obj_text(uv, xyz, faces, mode, "mesh", colors if mode == "color" else None)

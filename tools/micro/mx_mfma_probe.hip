@@ -52,8 +52,9 @@ static uint8_t e4m3(int v) {  // small integers, exact
 }
 
 int main() {
-    // Hypothesis H1: lane l, byte i of A <-> A[row l&15][k = 32*(l>>4) + i]; B the same with col l&15;
-    // lane l's scale byte (selected by opsel) scales its own 32 bytes; C: col = l&15, row = 4*(l>>4) + r.
+    // Layout found by mx_mfma_discover.hip: lane l = (r = l & 15, q = l >> 4), byte i of A <-> A[row r][k = 64*(i>>4) +
+    // 16*q + (i&15)]; B the same with col r; the scale byte (selected by op_sel) of lane r + 16*kb scales (row r, K
+    // block kb = k / 32); C: col = l&15, row = 4*(l>>4) + reg.
     std::vector<float> A(16 * 128), B(128 * 16);
     std::vector<uint8_t> a(64 * 32), b(64 * 32);
     std::vector<int> sa(64), sb(64);
@@ -73,8 +74,8 @@ int main() {
     for (int opsel = 0; opsel < 4; ++opsel) {
         for (int l = 0; l < 64; ++l) {
             for (int i = 0; i < 32; ++i) {
-                a[l * 32 + i] = e4m3((int)A[(l & 15) * 128 + 32 * (l >> 4) + i]);
-                b[l * 32 + i] = e4m3((int)B[(32 * (l >> 4) + i) * 16 + (l & 15)]);
+                a[l * 32 + i] = e4m3((int)A[(l & 15) * 128 + 64 * (i >> 4) + 16 * (l >> 4) + (i & 15)]);
+                b[l * 32 + i] = e4m3((int)B[(64 * (i >> 4) + 16 * (l >> 4) + (i & 15)) * 16 + (l & 15)]);
             }
             // the selected byte carries the scale; the other bytes carry junk that must be ignored
             unsigned wa = 0x11223344u, wb = 0x55667788u;
@@ -105,7 +106,7 @@ int main() {
                 if (d > 1e-3 * (fabs(ref) + 1)) ++bad;
                 if (d > worst) worst = d;
             }
-        printf("mx 16x16x128 e4m3, H1 layout, opsel %d: %s (bad %d / 256, worst abs diff %g)\n", opsel,
+        printf("mx 16x16x128 e4m3, discovered layout, opsel %d: %s (bad %d / 256, worst abs diff %g)\n", opsel,
                bad ? "FAIL" : "PASS", bad, worst);
         fails += bad != 0;
     }
