@@ -29,26 +29,44 @@ TFLOP_PER_IMAGE_FOV = 19.247
 TFLOP_PER_IMAGE_NOFOV = 18.865
 VIT_WINDOW_GFLOP = 382.13
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MFMA_PEAK_TFLOPS_FP8 = 5000.0  # dense MX-scaled fp8, MI355X_MICROARCH.md "Peak FP8 MFMA"
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: a PMC file is only quoted for the build it was collected on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "matrix-eyes_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "matrix-eyes_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_name):
-    """(HBM-side bytes per launch, algorithmic bytes per launch, MFMA utilisation) of the dominant kernel
-    from the committed rocprofv3 PMC passes (profiles/r01_pmc_kernels.json, written by
-    tools/pmc_collect.py: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/gemm_probe.py on
-    the shapes this kernel alternates between in the step).  Both counters are in KiB; on gfx950
-    FETCH_SIZE reports half of the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM), so it is
-    doubled; Infinity-Cache hits are included in it.  (None, None, None) for a kernel without a pass."""
+    """(HBM-side bytes per launch, algorithmic bytes per launch, MFMA utilisation, note) of the dominant kernel
+    from the committed rocprofv3 PMC passes (profiles/r02_pmc_kernels.json, written by tools/pmc_collect.py:
+    separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/gemm_probe.py on the shapes this kernel
+    alternates between in the step).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
+    of a wide coalesced stream (MI355X_MICROARCH.md, HBM), so it is doubled; Infinity-Cache hits are included in
+    it.  The file records the sha of the kernel sources it was collected on: a file from another build is
+    refused (traffic null), as is a kernel without a pass."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")))
-        ops = [v for v in pmc.values() if v.get("bench_kernel") == kernel_name]
+        pmc = json.load(open(PMC_FILE))
+        meta = pmc.get("_meta", {})
+        if meta.get("source_sha") != kernel_source_sha():
+            return None, None, None, f"PMC file is from another build (source sha {meta.get('source_sha')})"
+        ops = [v for k, v in pmc.items() if k != "_meta" and v.get("bench_kernel") == kernel_name]
         if not ops:
-            return None, None, None
+            return None, None, None, "no PMC pass for this kernel"
         n = float(len(ops))
         return (sum(v["hbm_bytes"] for v in ops) / n, sum(v["algorithmic_bytes"] for v in ops) / n,
-                sum(v["mfma_util"] for v in ops) / n)
-    except Exception:
-        return None, None, None
+                sum(v["mfma_util"] for v in ops) / n, f"profiles/r02_pmc_kernels.json, source sha {meta['source_sha']}")
+    except Exception as e:   # no file: traffic stays null
+        return None, None, None, f"no PMC file ({type(e).__name__})"
 
 
 def parse_args():
@@ -57,7 +75,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "fp8"],
+                    help="MFMA operand type: f16 (default; BASELINE configs[1], the fp16 checkpoint bit for bit), bf16, "
+                         "or fp8 (BASELINE configs[3]: the ViT linears on MX block-scaled fp8, the rest f16)")
     ap.add_argument("--no-fov", action="store_true", help="pass f_norm = 1 instead of the FOV head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1,
@@ -66,8 +86,10 @@ def parse_args():
 
 
 def cpu_baseline(cfg, weights, windows):
-    """The oracle's patch-encoder ViT-L over `windows` of the image's 35 windows, on the host cores;
-    scaled to images/s by its share of the image's algorithmic FLOPs."""
+    """The oracle's patch-encoder ViT-L over some of the image's 35 windows on the host cores, scaled to images/s
+    by its share of the image's algorithmic FLOPs.  Two samples: all host cores -- the figure in
+    `value` -- and ONE thread, which is what the reference's lockfile implies for its Burn-ndarray build
+    (matrixmultiply without the threading feature, Cargo.lock:643,3452); about 10 s of CPU work each."""
     import torch
     from oracle import depth_pro_oracle as O
     ocfg = O.OracleConfig(grid=cfg.grid, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads,
@@ -82,20 +104,29 @@ def cpu_baseline(cfg, weights, windows):
             O.vit_forward_features(xs, weights, "encoder.patch_encoder.", ocfg, list(cfg.tap_blocks))
             return time.perf_counter() - t0
 
-    dt = run(windows)
-    if dt < 8.0:      # aim at 10-30 s of CPU work
-        windows = int(min(35, max(windows + 1, round(windows * 15.0 / dt))))
-        dt = run(windows)
-    share = windows * VIT_WINDOW_GFLOP / 1e3 / TFLOP_PER_IMAGE_FOV
+    def sample(n, threads):
+        torch.set_num_threads(threads)
+        dt = run(n)
+        share = n * VIT_WINDOW_GFLOP / 1e3 / TFLOP_PER_IMAGE_FOV
+        return {"value": share / dt, "cores": threads,
+                "sample": (f"patch-encoder ViT-L over {n} of 35 windows = {n * VIT_WINDOW_GFLOP:.0f} GFLOP = "
+                           f"{share * 100:.2f}% of one image's {TFLOP_PER_IMAGE_FOV} TFLOP, {dt:.1f} s on {threads} "
+                           f"thread(s); scaled by that share")}, dt
+
+    all_threads = torch.get_num_threads()
+    multi, dt = sample(windows, all_threads)
+    if dt < 6.0:      # aim at about 10 s of CPU work per sample
+        multi, dt = sample(int(min(35, max(windows + 1, round(windows * 10.0 / dt)))), all_threads)
+    single, _ = sample(1, 1)          # one window = 382 GFLOP: ~10 s at single-thread sgemm rates
+    torch.set_num_threads(all_threads)
     return {
-        "value": share / dt,
+        "value": multi["value"],
         "unit": "depth-maps/s",
-        "cores": torch.get_num_threads(),
+        "cores": multi["cores"],
         "kind": "port",
-        "sample": (f"CPU oracle (PyTorch fp32 restatement of the reference; Burn-ndarray cannot be built "
-                   f"here): patch-encoder ViT-L over {windows} of 35 windows = "
-                   f"{windows * VIT_WINDOW_GFLOP:.0f} GFLOP = {share * 100:.2f}% of one image's "
-                   f"{TFLOP_PER_IMAGE_FOV} TFLOP, {dt:.1f} s; scaled by that share"),
+        "sample": ("CPU oracle (PyTorch fp32 restatement of the reference; Burn-ndarray cannot be built here): " +
+                   multi["sample"]),
+        "single_thread": {"value": single["value"], "unit": "depth-maps/s", "cores": 1, "sample": single["sample"]},
     }
 
 
@@ -177,6 +208,17 @@ def main():
         step()
     prof = ctx.profile_report()
     ctx.profile_enable(False)
+    # end to end as the boundary hands buffers over when the caller keeps them on the host: u8 image in pageable
+    # host memory in, f32 depth in host memory out, H2D + D2H and their synchronisation included (never `value`)
+    e2e_ms = None
+    if rank == 0:
+        rgb_host = rgb.cpu().numpy()
+        ctx.extract_depth(rgb_host, f_norm)
+        t1 = time.perf_counter()
+        n_e2e = max(3, min(10, args.steps))
+        for _ in range(n_e2e):
+            ctx.extract_depth(rgb_host, f_norm)
+        e2e_ms = (time.perf_counter() - t1) / n_e2e * 1e3
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,8 +233,9 @@ def main():
         dom = max(prof, key=lambda k: k["total_ms"])
         prof_ms = sum(k["total_ms"] for k in prof)
         dom_ms = dom["total_ms"] / dom["launches"]
-        traffic, alg_bytes, mfma_util = pmc_traffic(dom["kernel"])
+        traffic, alg_bytes, mfma_util, pmc_note = pmc_traffic(dom["kernel"])
         achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS_FP8 if "<fp8," in dom["kernel"] else MFMA_PEAK_TFLOPS
         step_ms = elapsed / args.steps * 1e3
         kernels = sorted(prof, key=lambda k: -k["total_ms"])
         out = {
@@ -203,14 +246,17 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3),
+            "end_to_end_ms_per_step": None if e2e_ms is None else round(e2e_ms, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE.json configs[1]: single 1536x1536 image, 16-bit MFMA HIP path on "
-                             "1xMI355X, depth map + FOV head" if (B == 1 and not args.no_fov) else
+                "workload": (("BASELINE.json configs[3] at one image: single 1536x1536 image, ViT linears on MX fp8 MFMA, "
+                              "the rest f16, depth map + FOV head" if args.dtype == "fp8" else
+                              "BASELINE.json configs[1]: single 1536x1536 image, 16-bit MFMA HIP path on "
+                              "1xMI355X, depth map + FOV head") if (B == 1 and not args.no_fov) else
                              f"{B} x 1536x1536 images per GPU per step, " +
                              ("f_norm given" if args.no_fov else "FOV head")),
                 "batch_per_gpu": B,
@@ -219,6 +265,9 @@ def main():
                 "f_norm": "1.0" if args.no_fov else "FOV head (mod.rs:343-358)",
                 "parallelism": f"image-parallel, {world} process(es), one per GPU; packed weights by one RCCL "
                                f"broadcast at start-up ({t_load:.1f} s incl. synthetic init)",
+                "end_to_end": "end_to_end_ms_per_step: u8 image in pageable host memory in, f32 depth in host memory out "
+                              "(H2D 7.1 MB + D2H 9.4 MB per image and their synchronisation included), rank 0",
+                "split_operands": cfg.split_operands,
                 "tflop_per_image": tflop_img,
                 "model_tflops": round(value * tflop_img, 1),
             },
@@ -228,10 +277,11 @@ def main():
                 "launches_per_step": dom["launches"] / args.steps,
                 "avg_launch_ms": round(dom_ms, 5),
                 "achieved": round(achieved, 1),
-                "peak": MFMA_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "frac": round(achieved / peak, 4),
                 "traffic": traffic,
+                "traffic_source": pmc_note,
                 "algorithmic_bytes": alg_bytes,
                 "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 3),
                 "share_of_profiled_kernel_time": round(dom["total_ms"] / prof_ms, 3),

@@ -600,7 +600,7 @@ int32_t me_mesh_index(me_ctx* ctx, const float* depth, int32_t width, int32_t he
     OutBuf of;
     if (faces) of = out_buf(ctx, faces, nt * 3 * 4, "out.faces");
     mesh_index_run(d, width, height, (int32_t*)ov.dev, faces ? (int32_t*)of.dev : nullptr, nvertices,
-                   nfaces, ctx->stream);
+                   nfaces, site_buf(ctx, "out.mesh.ws", mesh_workspace_bytes(width, height)), ctx->stream);
     finish(ctx, ov);
     if (faces && of.staged) {  // only the kept triangles are defined
         ME_HIP(hipMemcpyAsync(faces, of.dev, (size_t)*nfaces * 12, hipMemcpyDeviceToHost,

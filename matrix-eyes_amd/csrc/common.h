@@ -284,9 +284,10 @@ void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min
                        const uint8_t* noise, uint8_t* out, hipStream_t stream);
 void depthmap_rgb_launch(const float* depth, int64_t count, float min_depth, float max_depth,
                          const float* range_dev, uint8_t* rgb, hipStream_t stream);
-// synchronises the stream (the counts come back to the host)
+// synchronises the stream (the counts come back to the host); workspace: mesh_workspace_bytes() device bytes
+size_t mesh_workspace_bytes(int32_t width, int32_t height);
 void mesh_index_run(const float* depth_dev, int32_t width, int32_t height, int32_t* vertex_index_dev,
-                    int32_t* faces_dev /*nullable*/, int64_t* nverts, int64_t* nfaces,
+                    int32_t* faces_dev /*nullable*/, int64_t* nverts, int64_t* nfaces, void* workspace,
                     hipStream_t stream);
 void mesh_vertices_launch(const float* depth, int32_t width, int32_t height,
                           const int32_t* vertex_index, float xm, float ym, float* uv, float* xyz,

@@ -191,7 +191,8 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
         int32_t* vindex = (int32_t*)site_buf(ctx, "out.vindex", nv * 4);
         int32_t* faces_dev = (int32_t*)site_buf(ctx, "out.faces", nt * 12);
         int64_t nverts = 0, nfaces = 0;
-        mesh_index_run(d, width, height, vindex, faces_dev, &nverts, &nfaces, ctx->stream);
+        mesh_index_run(d, width, height, vindex, faces_dev, &nverts, &nfaces,
+                       site_buf(ctx, "out.mesh.ws", mesh_workspace_bytes(width, height)), ctx->stream);
         float* uv_dev = (float*)site_buf(ctx, "out.uv", nverts * 8 + 8);
         float* xyz_dev = (float*)site_buf(ctx, "out.xyz", nverts * 12 + 12);
         const uint32_t mx = original_width > original_height ? original_width : original_height;

@@ -29,27 +29,40 @@ __device__ __forceinline__ int64_t rs_as_usize(float v) {
     return (int64_t)v;
 }
 
-__global__ void clamp_minmax_kernel(float* __restrict__ depth, int64_t count,
-                                    unsigned* __restrict__ minmax) {
+// One atomic pair per workgroup: thousands of wave-level atomics on the same two words serialise in one L2
+// channel (0.19 ms for 16 K of them; the data itself is 19 MB).  16-byte accesses; the tail is scalar.
+__global__ __launch_bounds__(256) void clamp_minmax_kernel(float* __restrict__ depth, int64_t count,
+                                                           unsigned* __restrict__ minmax) {
     // output.rs:51-57 (clamp) and 69-75 (fold with f32::min / f32::max, which skip NaN)
+    __shared__ float smn[4], smx[4];
     const float lo = 1.0f / 250.0f, hi = 1.0f / 0.1f;
     float mn = INFINITY, mx = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    // a pointer off 16-byte alignment (a caller's slice) takes the scalar loop for everything
+    const int64_t n4 = ((size_t)depth & 15) == 0 ? count / 4 : 0;
+    float4* d4 = reinterpret_cast<float4*>(depth);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = d4[i];
+        v.x = rs_clamp(v.x, lo, hi), v.y = rs_clamp(v.y, lo, hi), v.z = rs_clamp(v.z, lo, hi), v.w = rs_clamp(v.w, lo, hi);
+        d4[i] = v;
+        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = rs_clamp(depth[i], lo, hi);
         depth[i] = v;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+        mn = fminf(mn, v), mx = fmaxf(mx, v);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, o));
         mx = fmaxf(mx, __shfl_xor(mx, o));
     }
+    if ((threadIdx.x & 63) == 0) smn[threadIdx.x >> 6] = mn, smx[threadIdx.x >> 6] = mx;
+    __syncthreads();
     // clamped values are positive, so the u32 order of the bit patterns is the float order
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&minmax[0], __float_as_uint(mn));
-        atomicMax(&minmax[1], __float_as_uint(mx));
+    if (threadIdx.x == 0) {
+        atomicMin(&minmax[0], __float_as_uint(fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]))));
+        atomicMax(&minmax[1], __float_as_uint(fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]))));
     }
 }
 
@@ -179,87 +192,111 @@ __device__ __forceinline__ bool tri_keep(float a, float b, float c) {
     return __fdiv_rn(mx, mn) <= 1.025f;
 }
 
-__global__ void mesh_keep_kernel(const float* __restrict__ depth, int width, int height,
-                                 uint8_t* __restrict__ keep) {
-    const int qw = width - 1;
-    const int64_t nq = (int64_t)qw * (height - 1);
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
-         q += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(q / qw), x = (int)(q - (int64_t)y * qw);
-        const float v00 = depth[(int64_t)y * width + x], v10 = depth[(int64_t)y * width + x + 1];
-        const float v01 = depth[(int64_t)(y + 1) * width + x];
-        const float v11 = depth[(int64_t)(y + 1) * width + x + 1];
-        keep[q] = (tri_keep(v00, v01, v10) ? 1 : 0) | (tri_keep(v10, v01, v11) ? 2 : 0);
-    }
-}
-
 constexpr uint32_t NO_KEY = 0xffffffffu;
 
-// smallest use key of vertex (y, x)
-__device__ __forceinline__ uint32_t vertex_first_key(const uint8_t* __restrict__ keep, int width,
-                                                     int height, int y, int x) {
+// Everything one quad needs, from the 4 x 4 depth patch around it: the keep bits of the 3 x 3 quads around q
+// (bit 2 * (3 * dy + dx) + tri for quad (y - 1 + dy, x - 1 + dx)); quads outside the grid keep nothing.
+__device__ __forceinline__ uint32_t quad_neighbourhood(const float* __restrict__ depth, int width, int height, int y, int x) {
     const int qw = width - 1, qh = height - 1;
+    float d[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(y - 1 + j, 0), height - 1), xx = min(max(x - 1 + i, 0), width - 1);
+            d[j][i] = depth[(int64_t)yy * width + xx];
+        }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int qy = y - 1 + dy, qx = x - 1 + dx;
+            if (qy < 0 || qx < 0 || qy >= qh || qx >= qw) continue;
+            const float v00 = d[dy][dx], v10 = d[dy][dx + 1], v01 = d[dy + 1][dx], v11 = d[dy + 1][dx + 1];
+            bits |= (tri_keep(v00, v01, v10) ? 1u : 0u) << (2 * (3 * dy + dx));
+            bits |= (tri_keep(v10, v01, v11) ? 1u : 0u) << (2 * (3 * dy + dx) + 1);
+        }
+    return bits;
+}
+
+// smallest use key of corner (cy, cx) in {0,1}^2 of quad (y, x), from that quad's neighbourhood bits: the <= 6
+// incident triangles in the order of their keys (output.rs:307-355 visits quads in raster order, the upper-left
+// triangle [i00, i01, i10] before the lower-right one [i10, i01, i11])
+__device__ __forceinline__ uint32_t corner_first_key(uint32_t bits, int width, int y, int x, int cy, int cx) {
+    const int qw = width - 1;
+    const int vy = y + cy, vx = x + cx;  // the vertex
     uint32_t best = NO_KEY;
     auto consider = [&](int qy, int qx, int tri, int slot) {
-        if (qy < 0 || qx < 0 || qy >= qh || qx >= qw) return;
-        const int64_t q = (int64_t)qy * qw + qx;
-        if (keep[q] & (1 << tri)) {
-            const uint32_t key = (uint32_t)(3 * (2 * q + tri) + slot);
+        const int dy = qy - (y - 1), dx = qx - (x - 1);  // position in the 3 x 3 neighbourhood (always inside it)
+        if (bits >> (2 * (3 * dy + dx) + tri) & 1u) {
+            const uint32_t key = (uint32_t)(3 * (2 * ((int64_t)qy * qw + qx) + tri) + slot);
             best = key < best ? key : best;
         }
     };
-    consider(y - 1, x - 1, 1, 2);  // i11 of the lower-right triangle
-    consider(y - 1, x, 0, 1);      // i01 of the upper-left triangle
-    consider(y - 1, x, 1, 1);      // i01 of the lower-right triangle
-    consider(y, x - 1, 0, 2);      // i10 of the upper-left triangle
-    consider(y, x - 1, 1, 0);      // i10 of the lower-right triangle
-    consider(y, x, 0, 0);          // i00 of the upper-left triangle
+    consider(vy - 1, vx - 1, 1, 2);  // i11 of the lower-right triangle
+    consider(vy - 1, vx, 0, 1);      // i01 of the upper-left triangle
+    consider(vy - 1, vx, 1, 1);      // i01 of the lower-right triangle
+    consider(vy, vx - 1, 0, 2);      // i10 of the upper-left triangle
+    consider(vy, vx - 1, 1, 0);      // i10 of the lower-right triangle
+    consider(vy, vx, 0, 0);          // i00 of the upper-left triangle
     return best;
 }
 
-__global__ void mesh_first_key_kernel(const uint8_t* __restrict__ keep, int width, int height,
-                                      uint32_t* __restrict__ first_key) {
-    const int64_t nv = (int64_t)width * height;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv;
-         v += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(v / width), x = (int)(v - (int64_t)y * width);
-        first_key[v] = vertex_first_key(keep, width, height, y, x);
-    }
+// Status word of the single-pass scan (decoupled look-back): bits 0-1 flag (0 nothing yet, 1 = this block's
+// aggregate, 2 = inclusive prefix up to and including this block), bits 2-32 vertices, bits 33-63 triangles.
+// One 8-byte word written by one agent-scope store carries its own validity: no fence is needed beside it.
+constexpr unsigned long long ST_AGG = 1, ST_PREFIX = 2;
+__device__ __forceinline__ unsigned long long st_pack(unsigned long long flag, uint32_t nv, uint32_t nf) {
+    return flag | ((unsigned long long)nv << 2) | ((unsigned long long)nf << 33);
 }
 
-// counts[q] = (kept triangles of q) << 32 | (vertices first used by q)
-__global__ void mesh_count_kernel(const uint8_t* __restrict__ keep,
-                                  const uint32_t* __restrict__ first_key, int width, int height,
-                                  unsigned long long* __restrict__ counts) {
-    const int qw = width - 1;
-    const int64_t nq = (int64_t)qw * (height - 1);
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
-         q += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(q / qw), x = (int)(q - (int64_t)y * qw);
-        const uint32_t lo = (uint32_t)(6 * q), hi = lo + 6;
-        int nv = 0;
-        const int64_t c[4] = {(int64_t)y * width + x, (int64_t)y * width + x + 1,
-                              (int64_t)(y + 1) * width + x, (int64_t)(y + 1) * width + x + 1};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t fk = first_key[c[k]];
-            nv += (fk >= lo && fk < hi) ? 1 : 0;
-        }
-        const int nf = (keep[q] & 1) + ((keep[q] >> 1) & 1);
-        counts[q] = ((unsigned long long)nf << 32) | (unsigned)nv;
-    }
-}
-
-// ---- exclusive scan of u64 (two packed u32 counters), 1024 elements per block ----
-__global__ __launch_bounds__(256) void scan_block_kernel(unsigned long long* __restrict__ data,
-                                                         int64_t n,
-                                                         unsigned long long* __restrict__ block_sums) {
+// ONE pass over the quads in raster order, 1024 per workgroup (4 consecutive quads per thread): keep bits and
+// first-use counts from the depth map itself, a workgroup scan, a decoupled look-back across workgroups (taken
+// in ticket order, so every predecessor is running or done: no deadlock whatever the dispatch order), then the
+// vertex ids of the vertices each quad introduces and, per quad, (first face index << 2 | keep bits) for the
+// face kernel.  ws: [0] ticket, [1] total (vertices | triangles << 32), [2..] one status word per workgroup.
+__global__ __launch_bounds__(256) void mesh_scan_kernel(const float* __restrict__ depth, int width, int height,
+                                                        int32_t* __restrict__ vertex_index,
+                                                        uint32_t* __restrict__ quad_info,
+                                                        unsigned long long* __restrict__ ws) {
     __shared__ unsigned long long wsum[4];
-    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    unsigned long long v[4];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_block;
+    const int qw = width - 1, qh = height - 1;
+    const int64_t nq = (int64_t)qw * qh;
+    if (threadIdx.x == 0)
+        s_block = (unsigned)__hip_atomic_fetch_add(&ws[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned blk = s_block;
+    unsigned long long* status = ws + 2;
+    const int64_t q0 = (int64_t)blk * 1024 + threadIdx.x * 4;
+    uint32_t fk[4][4];
+    uint32_t keep[4];
+    unsigned long long cnt[4];  // vertices | triangles << 32
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = base + k < n ? data[base + k] : 0ull;
-    const unsigned long long tsum = v[0] + v[1] + v[2] + v[3];
+    for (int k = 0; k < 4; ++k) {
+        const int64_t q = q0 + k;
+        keep[k] = 0, cnt[k] = 0;
+        if (q >= nq) continue;
+        const int y = (int)(q / qw), x = (int)(q - (int64_t)y * qw);
+        const uint32_t bits = quad_neighbourhood(depth, width, height, y, x);
+        keep[k] = bits >> 8 & 3u;  // the centre quad
+        const uint32_t lo = (uint32_t)(6 * q), hi = lo + 6;
+        uint32_t nv = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            fk[k][c] = corner_first_key(bits, width, y, x, c >> 1, c & 1);  // c: i00, i10, i01, i11
+            nv += (fk[k][c] >= lo && fk[k][c] < hi) ? 1u : 0u;
+            // unused vertices get -1 from the quad whose i00 they are (last column / row: from its neighbour)
+            const bool mine = c == 0 || (c == 1 && x == qw - 1) || (c == 2 && y == qh - 1) ||
+                              (c == 3 && x == qw - 1 && y == qh - 1);
+            if (mine && fk[k][c] == NO_KEY) vertex_index[(int64_t)(y + (c >> 1)) * width + x + (c & 1)] = -1;
+        }
+        cnt[k] = (unsigned long long)nv | ((unsigned long long)((keep[k] & 1u) + (keep[k] >> 1)) << 32);
+    }
+    // exclusive scan inside the workgroup
+    const unsigned long long tsum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     unsigned long long inc = tsum;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -271,94 +308,77 @@ __global__ __launch_bounds__(256) void scan_block_kernel(unsigned long long* __r
     __syncthreads();
     unsigned long long woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
-    unsigned long long run = woff + inc - tsum;  // exclusive prefix of this thread
+    const unsigned long long block_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // decoupled look-back by wave 0: publish the aggregate, walk the predecessors 64 at a time
+    if (wave == 0) {
+        const uint32_t bv = (uint32_t)block_total, bf = (uint32_t)(block_total >> 32);
+        if (lane == 0)
+            __hip_atomic_store(&status[blk], st_pack(blk == 0 ? ST_PREFIX : ST_AGG, bv, bf), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long prefix = 0;  // vertices | triangles << 32 of all earlier workgroups
+        int64_t end = blk;              // predecessors [end - 64, end) are examined next
+        while (end > 0) {
+            const int64_t i = end - 1 - lane;
+            unsigned long long st = st_pack(ST_PREFIX, 0, 0);  // lanes past the start: neutral
+            if (i >= 0) {
+                do {
+                    st = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((st & 3ull) == 0);  // ticket order: that workgroup is running, the word will come
+            }
+            // the nearest lane holding an inclusive prefix ends the walk; sum everything up to and including it
+            const unsigned long long has_prefix = __ballot((st & 3ull) == ST_PREFIX);
+            const int stop = __ffsll((long long)has_prefix) - 1;  // first such lane (lane 0 = nearest predecessor)
+            const unsigned long long val = ((st >> 2) & 0x7fffffffull) | ((st >> 33) << 32);
+            unsigned long long part = (stop < 0 || lane <= stop) ? val : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            prefix += part;
+            if (stop >= 0) break;
+            end -= 64;
+        }
+        if (lane == 0) {
+            const unsigned long long incl = prefix + block_total;
+            if (blk != 0)
+                __hip_atomic_store(&status[blk], st_pack(ST_PREFIX, (uint32_t)incl, (uint32_t)(incl >> 32)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+            if ((int64_t)blk == (nq + 1023) / 1024 - 1) ws[1] = incl;  // the last workgroup: totals
+        }
+    }
+    __syncthreads();
+    unsigned long long run = s_prefix + woff + inc - tsum;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (base + k < n) data[base + k] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + inc;
-}
-
-__global__ __launch_bounds__(256) void scan_sums_kernel(unsigned long long* __restrict__ sums,
-                                                        int64_t nblocks,
-                                                        unsigned long long* __restrict__ total) {
-    // one workgroup, sequential over chunks of 256
-    __shared__ unsigned long long carry_s;
-    __shared__ unsigned long long wsum[4];
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t c = 0; c < nblocks; c += 256) {
-        const int64_t i = c + threadIdx.x;
-        const unsigned long long v = i < nblocks ? sums[i] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long woff = carry_s;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        if (i < nblocks) sums[i] = woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry_s;
-}
-
-__global__ void mesh_assign_kernel(const uint8_t* __restrict__ keep,
-                                   const uint32_t* __restrict__ first_key,
-                                   const unsigned long long* __restrict__ scanned,
-                                   const unsigned long long* __restrict__ block_sums, int width,
-                                   int height, int32_t* __restrict__ vertex_index) {
-    const int qw = width - 1;
-    const int64_t nq = (int64_t)qw * (height - 1);
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
-         q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = q0 + k;
+        if (q >= nq) break;
         const int y = (int)(q / qw), x = (int)(q - (int64_t)y * qw);
         const uint32_t lo = (uint32_t)(6 * q), hi = lo + 6;
-        const uint32_t vbase = (uint32_t)(scanned[q] + block_sums[q >> 10]);
-        const int64_t c[4] = {(int64_t)y * width + x, (int64_t)y * width + x + 1,
-                              (int64_t)(y + 1) * width + x, (int64_t)(y + 1) * width + x + 1};
-        uint32_t fk[4];
+        const uint32_t vbase = (uint32_t)run, fbase = (uint32_t)(run >> 32);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fk[k] = first_key[c[k]];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (fk[k] >= lo && fk[k] < hi) {
+        for (int c = 0; c < 4; ++c) {
+            if (fk[k][c] >= lo && fk[k][c] < hi) {
                 int rank = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rank += (fk[j] >= lo && fk[j] < fk[k]) ? 1 : 0;
-                vertex_index[c[k]] = (int32_t)(vbase + rank);
+                for (int j = 0; j < 4; ++j) rank += (fk[k][j] >= lo && fk[k][j] < fk[k][c]) ? 1 : 0;
+                vertex_index[(int64_t)(y + (c >> 1)) * width + x + (c & 1)] = (int32_t)(vbase + rank);
             }
         }
+        quad_info[q] = fbase << 2 | keep[k];
+        run += cnt[k];
     }
 }
 
-__global__ void mesh_unused_kernel(const uint32_t* __restrict__ first_key, int64_t nv,
-                                   int32_t* __restrict__ vertex_index) {
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv;
-         v += (int64_t)gridDim.x * blockDim.x)
-        if (first_key[v] == NO_KEY) vertex_index[v] = -1;
-}
-
-__global__ void mesh_faces_kernel(const uint8_t* __restrict__ keep,
-                                  const unsigned long long* __restrict__ scanned,
-                                  const unsigned long long* __restrict__ block_sums,
-                                  const int32_t* __restrict__ vertex_index, int width, int height,
-                                  int32_t* __restrict__ faces) {
+__global__ void mesh_faces_kernel(const uint32_t* __restrict__ quad_info, const int32_t* __restrict__ vertex_index,
+                                  int width, int height, int32_t* __restrict__ faces) {
     const int qw = width - 1;
     const int64_t nq = (int64_t)qw * (height - 1);
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq;
          q += (int64_t)gridDim.x * blockDim.x) {
-        const uint8_t k = keep[q];
+        const uint32_t info = quad_info[q];
+        const uint32_t k = info & 3u;
         if (!k) continue;
         const int y = (int)(q / qw), x = (int)(q - (int64_t)y * qw);
-        int64_t f = (int64_t)((scanned[q] + block_sums[q >> 10]) >> 32);
+        int64_t f = info >> 2;
         const int32_t i00 = vertex_index[(int64_t)y * width + x];
         const int32_t i10 = vertex_index[(int64_t)y * width + x + 1];
         const int32_t i01 = vertex_index[(int64_t)(y + 1) * width + x];
@@ -404,8 +424,8 @@ void depth_clamp_minmax_launch(float* depth, int64_t count, float* minmax_dev, h
     // {+inf, 0} as bit patterns, set on the stream without host memory (graph-capturable, no staging copy)
     ME_HIP(hipMemsetD32Async((hipDeviceptr_t)minmax_dev, 0x7f800000, 1, stream));
     ME_HIP(hipMemsetD32Async((hipDeviceptr_t)(minmax_dev + 1), 0, 1, stream));
-    unsigned g = grid_for(count);
-    g = g > 2048 ? 2048 : g;
+    unsigned g = grid_for(cdiv(count, 16));  // >= 16 elements per thread; at most one workgroup per CU pair
+    g = g > 512 ? 512 : g;
     hipLaunchKernelGGL(clamp_minmax_kernel, dim3(g), dim3(256), 0, stream, depth, count,
                        (unsigned*)minmax_dev);
     ME_HIP(hipGetLastError());
@@ -438,48 +458,33 @@ void depthmap_rgb_launch(const float* depth, int64_t count, float min_depth, flo
     ME_HIP(hipGetLastError());
 }
 
-void mesh_index_run(const float* depth, int32_t width, int32_t height, int32_t* vertex_index,
-                    int32_t* faces, int64_t* nverts, int64_t* nfaces, hipStream_t stream) {
-    ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "mesh: %dx%d", width, height);
-    const int64_t nv = (int64_t)width * height;
+size_t mesh_workspace_bytes(int32_t width, int32_t height) {
     const int64_t nq = (int64_t)(width - 1) * (height - 1);
-    ME_CHECK(6 * nq < 0xffffffffll, ME_ERR_BAD_SHAPE, "mesh: %dx%d too large", width, height);
+    return (size_t)((2 + cdiv(nq, 1024)) * 8 + 256 + nq * 4);
+}
+
+// Two launches (scan + faces), one 16-byte read-back of the counts.  `workspace`: mesh_workspace_bytes() of
+// device memory owned by the caller's context (no allocation here).
+void mesh_index_run(const float* depth, int32_t width, int32_t height, int32_t* vertex_index,
+                    int32_t* faces, int64_t* nverts, int64_t* nfaces, void* workspace, hipStream_t stream) {
+    ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "mesh: %dx%d", width, height);
+    const int64_t nq = (int64_t)(width - 1) * (height - 1);
+    // 30 bits of face index beside the keep bits in quad_info; 31-bit counters in the scan's status words
+    ME_CHECK(2 * nq < (1ll << 30), ME_ERR_BAD_SHAPE, "mesh: %dx%d too large", width, height);
     const int64_t nblocks = cdiv(nq, 1024);
-    uint8_t* keep = nullptr;
-    uint32_t* first_key = nullptr;
-    unsigned long long *counts = nullptr, *sums = nullptr;
-    // one-shot workspace: this is a per-image call outside the inference loop
-    ME_HIP(hipMalloc(&keep, nq));
-    ME_HIP(hipMalloc(&first_key, nv * 4));
-    ME_HIP(hipMalloc(&counts, nq * 8));
-    ME_HIP(hipMalloc(&sums, (nblocks + 1) * 8));
-    hipLaunchKernelGGL(mesh_keep_kernel, dim3(grid_for(nq)), dim3(256), 0, stream, depth, width,
-                       height, keep);
-    hipLaunchKernelGGL(mesh_first_key_kernel, dim3(grid_for(nv)), dim3(256), 0, stream, keep, width,
-                       height, first_key);
-    hipLaunchKernelGGL(mesh_count_kernel, dim3(grid_for(nq)), dim3(256), 0, stream, keep, first_key,
-                       width, height, counts);
-    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, counts, nq,
-                       sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, sums, nblocks,
-                       sums + nblocks);
-    hipLaunchKernelGGL(mesh_unused_kernel, dim3(grid_for(nv)), dim3(256), 0, stream, first_key, nv,
-                       vertex_index);
-    hipLaunchKernelGGL(mesh_assign_kernel, dim3(grid_for(nq)), dim3(256), 0, stream, keep, first_key,
-                       counts, sums, width, height, vertex_index);
+    unsigned long long* ws = (unsigned long long*)workspace;
+    const size_t head = ((size_t)(2 + nblocks) * 8 + 255) / 256 * 256;
+    uint32_t* quad_info = (uint32_t*)((char*)workspace + head);
+    ME_HIP(hipMemsetAsync(ws, 0, (size_t)(2 + nblocks) * 8, stream));  // ticket, total, status words
+    hipLaunchKernelGGL(mesh_scan_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, depth, width, height,
+                       vertex_index, quad_info, ws);
     if (faces)
-        hipLaunchKernelGGL(mesh_faces_kernel, dim3(grid_for(nq)), dim3(256), 0, stream, keep, counts,
-                           sums, vertex_index, width, height, faces);
-    hipError_t e = hipGetLastError();
+        hipLaunchKernelGGL(mesh_faces_kernel, dim3(grid_for(nq)), dim3(256), 0, stream, quad_info, vertex_index,
+                           width, height, faces);
+    ME_HIP(hipGetLastError());
     unsigned long long total = 0;
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(&total, sums + nblocks, 8, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(keep);
-    (void)hipFree(first_key);
-    (void)hipFree(counts);
-    (void)hipFree(sums);
-    ME_HIP(e);
+    ME_HIP(hipMemcpyAsync(&total, ws + 1, 8, hipMemcpyDeviceToHost, stream));
+    ME_HIP(hipStreamSynchronize(stream));
     *nverts = (int64_t)(total & 0xffffffffull);
     *nfaces = (int64_t)(total >> 32);
 }

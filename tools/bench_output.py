@@ -55,6 +55,9 @@ def main():
     d2 = depth.clone()
     ms = timeit(ctx, lambda: lib.me_depth_clamp_minmax(h, ptr(d2), S * S, C.byref(mn), C.byref(mx)))
     add("depth_clamp_minmax", ms, S * S * 8, "read + write f32; includes the 8-byte D2H of the range")
+    mm = torch.empty(2, dtype=torch.float32, device="cuda")
+    ms = timeit(ctx, lambda: lib.me_depth_clamp_minmax_async(h, ptr(d2), S * S, ptr(mm)))
+    add("depth_clamp_minmax_async", ms, S * S * 8, "read + write f32; the range stays on the device (no host round trip)")
     rgb = torch.empty(S, S, 3, dtype=torch.uint8, device="cuda")
     ms = timeit(ctx, lambda: lib.me_depthmap_rgb(h, ptr(d2), S * S, mn.value, mx.value, ptr(rgb)))
     add("depthmap_rgb", ms, S * S * 7, "f32 in, rgb8 out")
@@ -62,6 +65,9 @@ def main():
     out = torch.empty_like(noise)
     ms = timeit(ctx, lambda: lib.me_stereogram(h, ptr(d2), S, S, mn.value, mx.value, S, S, C.c_float(1.0 / 16.0), ptr(noise), ptr(out)))
     add("stereogram", ms, S * S * (4 + 3 + 3), "depth f32 + noise rgb8 in, rgb8 out")
+    ms = timeit(ctx, lambda: (lib.me_depth_clamp_minmax_async(h, ptr(d2), S * S, ptr(mm)),
+                              lib.me_stereogram_dev_range(h, ptr(d2), S, S, ptr(mm), S, S, C.c_float(1.0 / 16.0), ptr(noise), ptr(out))))
+    add("clamp + stereogram chained on the device", ms, S * S * (8 + 4 + 3 + 3), "DepthMap::new -> output_stereogram without a host round trip")
     vidx = torch.empty(S * S, dtype=torch.int32, device="cuda")
     nv, nf = C.c_int64(), C.c_int64()
     faces = torch.empty((S - 1) * (S - 1) * 2 * 3, dtype=torch.int32, device="cuda")
@@ -71,8 +77,8 @@ def main():
     xyz = torch.empty(nv.value * 3, dtype=torch.float32, device="cuda")
     ms = timeit(ctx, lambda: lib.me_mesh_vertices(h, ptr(d2), S, S, ptr(vidx), nv.value, S, S, ptr(uv), ptr(xyz)))
     add("mesh_vertices", ms, S * S * 8 + nv.value * 20, "depth + ids in, uv + xyz out")
-    if len(sys.argv) > 1:
-        json.dump(res, open(sys.argv[1], "w"), indent=1)
+    out_json = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r02_output_kernels.json")
+    json.dump(res, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -35,6 +35,23 @@ def main():
             f = lambda: lib.me_op_linear_residual(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(x32), cfg)
         else:
             f = lambda: lib.me_op_linear(h, M, N, K, ptr(a), ptr(w), ptr(bias), ptr(out16), None, 1 if op == "fc1" else 0, cfg)
+    elif op in ("qkv8", "fc1_8", "fc2_8"):     # MX fp8 operands (csrc/gemm_fp8.hip)
+        N, K = {"qkv8": (3072, 1024), "fc1_8": (4096, 1024), "fc2_8": (1024, 4096)}[op]
+        a = torch.randn(M, K, device="cuda").to(t16)
+        w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(t16)
+        bias = torch.randn(N, device="cuda"); gamma = torch.rand(N, device="cuda"); x32 = torch.randn(M, N, device="cuda")
+        out16 = torch.empty(M, N, dtype=t16, device="cuda")
+        a8 = torch.empty(M, K, dtype=torch.uint8, device="cuda"); asc = torch.zeros(M * K // 32, dtype=torch.uint8, device="cuda")
+        w8 = torch.empty(N, K, dtype=torch.uint8, device="cuda"); wsc = torch.zeros(N * K // 32, dtype=torch.uint8, device="cuda")
+        o8 = torch.empty(M, N, dtype=torch.uint8, device="cuda"); osc = torch.zeros(M * N // 32, dtype=torch.uint8, device="cuda")
+        assert lib.me_op_quantize_fp8(h, ptr(a), M, K, 0, ptr(a8), ptr(asc)) == 0
+        assert lib.me_op_quantize_fp8(h, ptr(w), N, K, 1, ptr(w8), ptr(wsc)) == 0
+        if op == "qkv8":
+            f = lambda: lib.me_op_linear_fp8(h, M, N, K, ptr(a8), ptr(asc), ptr(w8), ptr(wsc), ptr(bias), ptr(out16), None, None, None, None)
+        elif op == "fc1_8":
+            f = lambda: lib.me_op_linear_fp8(h, M, N, K, ptr(a8), ptr(asc), ptr(w8), ptr(wsc), ptr(bias), None, ptr(o8), ptr(osc), None, None)
+        else:
+            f = lambda: lib.me_op_linear_fp8(h, M, N, K, ptr(a8), ptr(asc), ptr(w8), ptr(wsc), ptr(bias), None, None, None, ptr(gamma), ptr(x32))
     elif op == "conv768":
         Hh = 768
         xb = torch.randn(1, Hh + 2, Hh + 2, 256, device="cuda").to(t16)

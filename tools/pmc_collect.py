@@ -26,6 +26,7 @@ DEFAULT = ["qkv:0", "fc1:0", "proj:0", "fc2:0", "conv768:0", "attn:0"]
 CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6"}
 PROBE_M = 21760   # tools/gemm_probe.py's default rows
 SHAPES = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
+SHAPES8 = {"qkv8": (3072, 1024), "fc1_8": (4096, 1024), "fc2_8": (1024, 4096)}   # MX fp8 operands
 
 
 def describe(op, cfg):
@@ -36,11 +37,17 @@ def describe(op, cfg):
         out = PROBE_M * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
         bytes_ = PROBE_M * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
+    if op in SHAPES8:
+        n, k = SHAPES8[op]
+        resid = op == "fc2_8"
+        out = PROBE_M * n * (8 if resid else (2 if op == "qkv8" else 1 + 1 / 32))
+        bytes_ = PROBE_M * k * (1 + 1 / 32) + n * k * (1 + 1 / 32) + out + n * 4 * (2 if resid else 1)
+        return f"gemm_kernel<fp8,256x256x128/8w-pp,plain,{'resid_scale' if resid else 'store'}>", int(bytes_)
     if op == "conv768":   # 16-bit bordered input, weights, f32 residual in, f32 + 16-bit out
         px = 768 * 768
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},conv,store>", 770 * 770 * 256 * 2 + 256 * 2304 * 2 + px * 256 * (4 + 4 + 2)
     return "attention_kernel", 35 * 577 * (3072 + 1024) * 2
-KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_ring_kernel", "attention_kernel")
+KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_kernel", "attention_kernel")
 
 
 def run_pass(op, cfg, counters, work):
@@ -89,6 +96,11 @@ def main():
         entry["tile_config"] = int(cfg)
         entry["bench_kernel"], entry["algorithmic_bytes"] = describe(op, int(cfg))
         result[op] = entry
+    sys.path.insert(0, ROOT)
+    import bench
+    result["_meta"] = {"source_sha": bench.kernel_source_sha(),
+                       "note": "sha256[:16] over matrix-eyes_amd/csrc/*.h + *.hip of the build these passes ran on; "
+                               "bench.py quotes roofline.traffic from this file only when its own build has the same sha"}
     json.dump(result, open(out_json, "w"), indent=1)
     print(json.dumps(result, indent=1))
 
