@@ -354,6 +354,7 @@ void quantize_f16_to_fp8_launch(const void* src16, uint8_t* dst8, uint8_t* scale
     if (weight_layout) ME_CHECK(rows % 64 == 0, ME_ERR_BAD_SHAPE, "fp8 quantise: %lld weight rows", (long long)rows);
     const int64_t tiles = weight_layout ? rows / 64 : cdiv(rows, 128);
     const int64_t total = rows * (K / 32);
+    ProfScope prof(stream, "quantize_f16_kernel", 0.0, (double)rows * K * 3.03);
     const int64_t g = cdiv(total, 256);
     hipLaunchKernelGGL(quantize_f16_kernel, dim3((unsigned)(g > 65535 ? 65535 : g)), dim3(256), 0, stream,
                        (const f16*)src16, dst8, scales, rows, K, tiles, weight_layout);

@@ -36,10 +36,10 @@ struct WeightSlot {
 struct VitBlockW {
     const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ls1, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls2;
     const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
-    // ME_DTYPE_FP8: MX fp8 copies of the three big linears (e4m3 bytes [N][K] + e8m0 block scales in the weight
+    // ME_DTYPE_FP8: MX fp8 copies of the four linears (e4m3 bytes [N][K] + e8m0 block scales in the weight
     // layout of mx_fp8.h), quantised on the device from the 16-bit arena when the weights are finalized
     const uint8_t *qkv_w8 = nullptr, *qkv_ws = nullptr, *fc1_w8 = nullptr, *fc1_ws = nullptr, *fc2_w8 = nullptr,
-                  *fc2_ws = nullptr;
+                  *fc2_ws = nullptr, *proj_w8 = nullptr, *proj_ws = nullptr;
 };
 struct VitW {
     const void* patch_w;

@@ -267,7 +267,7 @@ struct MergedVit {
     char *xn, *qkv, *att, *hid, *fin16;
     float* fin32 = nullptr;
     // ME_DTYPE_FP8: xn and hid hold e4m3 bytes, with their block scales (activation layout, Rtot / 128 tiles)
-    uint8_t *xn_s = nullptr, *hid_s = nullptr;
+    uint8_t *xn_s = nullptr, *hid_s = nullptr, *att8 = nullptr, *att_s = nullptr;
     RowSegs segs;
 
     static int64_t pad256(int64_t r) { return (r + 255) / 256 * 256; }
@@ -290,6 +290,8 @@ struct MergedVit {
         if (ctx->fp8) {
             xn_s = (uint8_t*)site_buf(ctx, "vitm.xn.scale", (size_t)Rtot * C / 32);
             hid_s = (uint8_t*)site_buf(ctx, "vitm.hid.scale", (size_t)Rtot * 4 * C / 32);
+            att8 = (uint8_t*)site_buf(ctx, "vitm.att8", (size_t)Rtot * C);
+            att_s = (uint8_t*)site_buf(ctx, "vitm.att.scale", (size_t)Rtot * C / 32);
         }
         fin16 = (char*)site_buf(ctx, "vitm.final16", (size_t)Rtot * C * 2);
         segs.seg1 = seg1, segs.seg2 = seg2, segs.win0 = W0, segs.win1 = W1;
@@ -350,11 +352,12 @@ struct MergedVit {
 
     // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales
     void gemm8(const void* A8, const uint8_t* As, int K, int N, const VitBlockW& b0, const VitBlockW& b1,
-               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2*/) {
+               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2, 3 proj*/) {
         GemmParams p = base_params();
-        auto w8 = [&](const VitBlockW& b) { return which == 0 ? b.qkv_w8 : (which == 1 ? b.fc1_w8 : b.fc2_w8); };
-        auto ws = [&](const VitBlockW& b) { return which == 0 ? b.qkv_ws : (which == 1 ? b.fc1_ws : b.fc2_ws); };
-        auto bias = [&](const VitBlockW& b) { return which == 0 ? b.qkv_b : (which == 1 ? b.fc1_b : b.fc2_b); };
+        auto w8 = [&](const VitBlockW& b) { return which == 0 ? b.qkv_w8 : (which == 1 ? b.fc1_w8 : (which == 2 ? b.fc2_w8 : b.proj_w8)); };
+        auto ws = [&](const VitBlockW& b) { return which == 0 ? b.qkv_ws : (which == 1 ? b.fc1_ws : (which == 2 ? b.fc2_ws : b.proj_ws)); };
+        auto bias = [&](const VitBlockW& b) { return which == 0 ? b.qkv_b : (which == 1 ? b.fc1_b : (which == 2 ? b.fc2_b : b.proj_b)); };
+        auto gamma = [&](const VitBlockW& b) { return which == 3 ? b.ls1 : b.ls2; };
         p.M = (int)Rtot, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = As, p.a_mt = (int)(Rtot / 128);
         p.W = w8(b0), p.w_scale = ws(b0), p.bias = bias(b0), p.ldc = N;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2;
@@ -367,7 +370,7 @@ struct MergedVit {
             p.act = ACT_GELU, p.out8 = (uint8_t*)hid, p.out8_scale = hid_s, p.out8_mt = (int)(Rtot / 128);
             gemm_fp8_launch(p, EPI_STORE, s);
         } else {
-            p.gamma = b0.ls2, p.gamma_s1 = b1.ls2, p.gamma_s2 = b2.ls2, p.res32 = tok, p.out32 = tok;
+            p.gamma = gamma(b0), p.gamma_s1 = gamma(b1), p.gamma_s2 = gamma(b2), p.res32 = tok, p.out32 = tok;
             gemm_fp8_launch(p, EPI_RESID_SCALE, s);
         }
     }
@@ -377,13 +380,14 @@ struct MergedVit {
         const VitBlockW &b0 = v0.blocks[i], &b1 = v1.blocks[i], &b2 = v2.blocks[i];
         const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
         if (ctx->fp8) {
-            // BASELINE configs[3]: LayerNorm writes MX fp8, qkv / fc1 / fc2 run on the scaled fp8 MFMA; attention
-            // and its projection stay f16 (the attention kernel's operands and output are 16-bit)
+            // BASELINE configs[3]: LayerNorm writes MX fp8, the four linears run on the scaled fp8 MFMA; attention
+            // itself stays f16 (q, k, v and its output are 16-bit; the output is quantised for the projection)
             set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
             layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
             gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
             attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
-            resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
+            quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
+            gemm8(att8, att_s, C, C, b0, b1, b2, 3);
             set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
             layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
             gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1);

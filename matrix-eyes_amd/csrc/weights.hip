@@ -393,7 +393,7 @@ void load_checkpoint_pt(me_ctx* ctx, const char* path) {
     finalize_weights(ctx);
 }
 
-// ME_DTYPE_FP8: quantise qkv / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
+// ME_DTYPE_FP8: quantise qkv / proj / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
 // to MX fp8 on the device.  Derived data: a rank that received the arena by broadcast rebuilds it itself.
 void build_fp8_weights(me_ctx* ctx) {
     if (!ctx->fp8) return;
@@ -409,6 +409,7 @@ void build_fp8_weights(me_ctx* ctx) {
             items.push_back({b.qkv_w, 3 * C, C, &b.qkv_w8, &b.qkv_ws});
             items.push_back({b.fc1_w, 4 * C, C, &b.fc1_w8, &b.fc1_ws});
             items.push_back({b.fc2_w, C, 4 * C, &b.fc2_w8, &b.fc2_ws});
+            items.push_back({b.proj_w, C, C, &b.proj_w8, &b.proj_ws});
         }
     size_t total = 0;
     for (const Item& it : items) total += align_up((size_t)it.N * it.K, 256) + align_up((size_t)it.N * it.K / 32, 256);
