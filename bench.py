@@ -117,7 +117,7 @@ def cpu_baseline(cfg, weights, windows):
     multi, dt = sample(windows, all_threads)
     if dt < 6.0:      # aim at about 10 s of CPU work per sample
         multi, dt = sample(int(min(35, max(windows + 1, round(windows * 10.0 / dt)))), all_threads)
-    single, _ = sample(1, 1)          # one window = 382 GFLOP: ~10 s at single-thread sgemm rates
+    single, _ = sample(3, 1)          # three windows = 1146 GFLOP: ~10 s at one core's sgemm rate
     torch.set_num_threads(all_threads)
     return {
         "value": multi["value"],

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,30 @@ struct Error {
     } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Per-kernel launch configuration that must be set up once PER DEVICE (dynamic-LDS attribute, resident
+// workgroup count): contexts may live on several devices, and on several host threads, of one process.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+    std::atomic<int> value[kMaxDevices];
+    PerDeviceOnce() {
+        for (auto& v : value) v.store(0, std::memory_order_relaxed);
+    }
+};
+// value cached for the current device (0 = not configured yet); `configure` returns the value to cache (> 0).
+// Two threads racing on the same device both configure (idempotent HIP calls) and store the same value.
+template <typename F>
+static inline int per_device_once(PerDeviceOnce& once, F&& configure) {
+    int dev = 0;
+    ME_HIP(hipGetDevice(&dev));
+    ME_CHECK(dev >= 0 && dev < kMaxDevices, ME_ERR_BAD_ARG, "device ordinal %d out of range", dev);
+    int v = once.value[dev].load(std::memory_order_acquire);
+    if (!v) {
+        v = configure(dev);
+        once.value[dev].store(v, std::memory_order_release);
+    }
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).

@@ -1059,18 +1059,16 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = (2 * BM + 3 * BN) * 128;
     ME_CHECK(p.K >= 128, ME_ERR_BAD_SHAPE, "gemm: the two-group kernel needs K >= 128 (K = %d)", p.K);
     auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
-    static int resident = 0;
-    if (!resident) {
+    static PerDeviceOnce once;
+    const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        int per_cu = 0, dev = 0, cus = 0;
+        int per_cu = 0, cus = 0;
         ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, smem));
-        ME_HIP(hipGetDevice(&dev));
         ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        per_cu = per_cu < 1 ? 1 : per_cu;
-        resident = per_cu * cus;
-        resident -= resident % 8;
-        resident = resident < 8 ? 8 : resident;
-    }
+        int r = (per_cu < 1 ? 1 : per_cu) * cus;
+        r -= r % 8;
+        return r < 8 ? 8 : r;
+    });
     const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
@@ -1083,20 +1081,16 @@ template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
 void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
     auto kern = gemm_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
-    static int resident = 0;  // workgroups that fit on the chip at once (per instantiation)
-    if (!resident) {
-        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   smem));
-        int per_cu = 0, dev = 0, cus = 0;
-        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, WM * WN * 64,
-                                                            smem));
-        ME_HIP(hipGetDevice(&dev));
+    static PerDeviceOnce once;  // workgroups that fit on the chip at once (per instantiation and device)
+    const int resident = per_device_once(once, [&](int dev) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int per_cu = 0, cus = 0;
+        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, WM * WN * 64, smem));
         ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        per_cu = per_cu < 1 ? 1 : per_cu;
-        resident = per_cu * cus;
-        resident -= resident % 8;  // whole XCD rounds: workgroup b always lands on XCD b % 8
-        resident = resident < 8 ? 8 : resident;
-    }
+        int r = (per_cu < 1 ? 1 : per_cu) * cus;
+        r -= r % 8;  // whole XCD rounds: workgroup b always lands on XCD b % 8
+        return r < 8 ? 8 : r;
+    });
     const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
@@ -1257,11 +1251,11 @@ template <typename T, int BM, int BN, int WM, int WN, int NST, int AMODE, int EP
 void gemm_launch_ring(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = NST * (BM + BN) * 128;
     auto kern = gemm_ring_kernel<T, BM, BN, WM, WN, NST, AMODE, EPI>;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce once;
+    per_device_once(once, [&](int) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        configured = true;
-    }
+        return 1;
+    });
     const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);

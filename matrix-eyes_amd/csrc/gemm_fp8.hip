@@ -270,21 +270,18 @@ template <int EPI, int OUT8>
 static void launch_pp8(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = (2 * 256 + 3 * 256) * 128;
     auto kern = gemm_pp8_kernel<EPI, OUT8>;
-    static int resident[16] = {0};
-    int dev = 0;
-    ME_HIP(hipGetDevice(&dev));
-    ME_CHECK(dev >= 0 && dev < 16, ME_ERR_BAD_ARG, "device %d", dev);
-    if (!resident[dev]) {
+    static PerDeviceOnce once;
+    const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         int per_cu = 0, cus = 0;
         ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, smem));
         ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         int r = (per_cu < 1 ? 1 : per_cu) * cus;
         r -= r % 8;
-        resident[dev] = r < 8 ? 8 : r;
-    }
+        return r < 8 ? 8 : r;
+    });
     const int64_t ntiles = cdiv(p.M, 256) * (p.N / 256);
-    const int64_t grid = ntiles < resident[dev] ? ntiles : resident[dev];
+    const int64_t grid = ntiles < resident ? ntiles : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
     ME_HIP(hipGetLastError());
 }

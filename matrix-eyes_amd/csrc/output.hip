@@ -440,12 +440,12 @@ void stereogram_launch(const float* depth, int32_t rows, int32_t cols, float min
     int rounds = 1;
     while ((1 << rounds) < out_w) ++rounds;
     const size_t lds = (size_t)out_w * 2 * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    per_device_once(once, [&](int) {
         ME_HIP(hipFuncSetAttribute((const void*)stereogram_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 2 * 4));
-        attr_set = true;
-    }
+        return 1;
+    });
     hipLaunchKernelGGL(stereogram_kernel, dim3(out_h), dim3(256), lds, stream, depth, rows, cols,
                        min_depth, max_depth, range_dev, out_w, out_h, amplitude, noise, out, rounds);
     ME_HIP(hipGetLastError());

@@ -59,7 +59,8 @@ Device::Device() {
         cfg.dec_dim = 256, cfg.head_dims[0] = 32, cfg.head_dims[1] = 1;
     }
     image_size_ = 64 * cfg.grid;
-    const int32_t rc = me_ctx_create(dev ? std::atoi(dev) : 0, dt && std::strcmp(dt, "bf16") == 0 ? ME_DTYPE_BF16 : ME_DTYPE_F16,
+    const int32_t dtype = dt && std::strcmp(dt, "bf16") == 0 ? ME_DTYPE_BF16 : (dt && std::strcmp(dt, "fp8") == 0 ? ME_DTYPE_FP8 : ME_DTYPE_F16);
+    const int32_t rc = me_ctx_create(dev ? std::atoi(dev) : 0, dtype,
                                      &cfg, &ctx_);
     if (rc != ME_OK) throw ModelError(rc, std::string("cannot initialise the HIP device: ") + me_last_error(nullptr));
 }

@@ -4,6 +4,7 @@ uses the `image` and `kamadak-exif` crates); at the native 1536x1536 size the re
 The u8 -> float normalisation and HWC -> CHW (reconstruction.rs:114-124) run on the GPU
 (`me_extract_depth_u8`)."""
 import math
+import os
 import sys
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -54,7 +55,7 @@ class SourceImage:                          # reconstruction.rs:74-81
             value = exif.get_ifd(_EXIF_IFD).get(_FOCAL_LENGTH_35MM, exif.get(_FOCAL_LENGTH_35MM))
         except Exception:
             return None
-        return float(value) if value else None
+        return float(value) if value is not None else None     # the reference keeps Some(0) (reconstruction.rs:136-143)
 
     def focal_length_px(self) -> Optional[float]:
         """reconstruction.rs:145-152: f_img / f_35mm == diagonal / diagonal(24 mm x 36 mm)"""
@@ -76,7 +77,7 @@ def extract_depth(device: int, model_loader: DepthProModelLoader, source_path: s
         raise
     f_px = img.focal_length_px()
     f_norm = None if f_px is None else float(np.float32(f_px / float(img.original_size[0])))   # :174-176
-    ctx = model_loader.context(device)
+    ctx = model_loader.context(device, os.environ.get("MATRIX_EYES_DTYPE", "f16"))   # f16 | bf16 | fp8, as the C++ twin
     ctx.set_progress(progress)
     try:
         inverse_depth = ctx.extract_depth(img.rgb8[None], f_norm)[0]
