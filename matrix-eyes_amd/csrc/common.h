@@ -179,6 +179,7 @@ struct GemmParams {
     // stored lo_off16 elements further on, so that a consumer whose K axis reads [hi | lo] against
     // duplicated weights sees v to ~2^-22 instead of 2^-11.  0: plain 16-bit output.
     int32_t lo_off16;
+    int32_t hi2_off16;     // with lo_off16: a second copy of hi this many elements on ([hi | lo | hi] operands)
     int32_t act;           // activation applied to the f16 output (and f32 for EPI_STORE)
     int32_t act16_only;    // 1: activation only on the out16 copy (out32 stays raw)
     int32_t out16_border;  // EPI_STORE/EPI_CONVT: out16 is zero-bordered [B][out_H+2][out_W+2][C]

@@ -310,6 +310,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                     : (int64_t)m * ld16;
             store_16bit<T>((T*)p.out16 + row16 + n, a, hi_ok);
             if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + row16 + n + p.lo_off16, a, hi_ok);
+            if (p.hi2_off16) store_16bit<T>((T*)p.out16 + row16 + n + p.hi2_off16, a, hi_ok);
         }
     } else if constexpr (EPI == EPI_RESID_SCALE) {
         const int64_t row32 = (int64_t)m * p.ldc;

@@ -61,6 +61,10 @@ struct FusionW {
     const void* deconv;  // null at level 0
     const void* out_w;
     const float* out_b;
+    // SPLIT_FUSION_OUT, levels 1-4: out_conv o deconv composed into ONE ConvTranspose (both are linear and
+    // nothing sits between them, decoder.rs:95-101), packed [(dy,dx,co)][W_hi | W_hi | W_lo] against [hi | lo | hi]
+    // activations; null when the two run as separate launches
+    const void* fused_w = nullptr;
 };
 struct ModelW {
     VitW vit[3];
@@ -124,6 +128,10 @@ struct me_ctx {
     bool finalized = false;
     me::ModelW w;
     std::vector<std::string> unused_weights;  // checkpoint keys me_load_checkpoint_pt skipped
+    // derived weights (composed deconv + out_conv per fusion level): arena offsets, and the host copies of their
+    // two factors kept from me_load_weight until me_weights_finalize composes them
+    size_t fused_off[5] = {0, 0, 0, 0, 0};
+    std::map<std::string, std::vector<float>> factor_keep;
 
     // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
     std::map<std::string, me::DevBuf> bufs;

@@ -88,6 +88,7 @@ struct ConvOut {
     void* out16 = nullptr;    // 16-bit copy
     bool border16 = false;    // out16 is [B][H+2][W+2][Cout]
     bool split16 = false;     // out16 pixels are [hi | lo] of 2*Cout
+    bool triple16 = false;    // ... [hi | lo | hi] of 3*Cout (with split16)
     int act = ACT_NONE;       // applied to out16 (and out32 unless act16_only)
     bool act16_only = true;
     const float* res32 = nullptr;
@@ -107,6 +108,7 @@ void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, cons
     p.out32 = o.out32, p.out16 = o.out16, p.ldc = Cout, p.out16_border = o.border16 ? 1 : 0;
     p.act = o.act, p.act16_only = o.act16_only ? 1 : 0;
     if (o.split16) set_out16_split(p, Cout);
+    if (o.triple16) p.ldc16 = 3 * Cout, p.hi2_off16 = 2 * Cout;
     gemm_launch(p, A_CONV, EPI_STORE, ctx->dtype, s);
 }
 
@@ -115,9 +117,10 @@ void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, cons
 // out_split: out16 pixels are [hi | lo], the lo part lo_off channels after the hi part (0: Cout)
 void convt(me_ctx* ctx, const void* in16, int B, int H, int W_, int Cin, const void* W, int Cout,
            const float* bias, float* out32, void* out16, bool border16, int64_t pixel_stride,
-           int act16, hipStream_t s, bool a_split = false, bool out_split = false, int64_t lo_off = 0) {
+           int act16, hipStream_t s, bool a_split = false, bool out_split = false, int64_t lo_off = 0,
+           int k_copies = 0 /* > 0: A rows hold this many Cin-wide parts ([hi | lo | hi] = 3) */) {
     GemmParams p = base_params();
-    const int Kx = a_split ? 2 * Cin : Cin;
+    const int Kx = k_copies > 0 ? k_copies * Cin : (a_split ? 2 * Cin : Cin);
     p.M = B * H * W_, p.N = 4 * Cout, p.K = Kx, p.A = in16, p.lda = Kx, p.W = W, p.bias = bias;
     p.out_H = H, p.out_W = W_, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
     p.out16_border = border16 ? 1 : 0, p.ldc = Cout, p.act = act16;
@@ -580,12 +583,22 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
         ConvOut o3;
         o3.out16 = t2_r16, o3.border16 = true, o3.act = ACT_RELU;
         conv(ctx, out_r16, B, h, h, dec, fw.resnet2.w[0], dec, 3, 1, fw.resnet2.b[0], o3, s);
-        // the operands of deconv and out_conv have no residual path beside them: [hi | lo] under SPLIT_FUSION_OUT
-        const size_t wf = spf ? 2 : 1;
+        // the operands of deconv and out_conv have no residual path beside them: [hi | lo] under SPLIT_FUSION_OUT,
+        // [hi | lo | hi] where the two are composed into one ConvTranspose (FusionW::fused_w)
+        const bool fused = spf && fw.deconv && fw.fused_w;
+        const size_t wf = fused ? 3 : (spf ? 2 : 1);
         void* v16 = site_buf(ctx, L + ".v16", (size_t)B * h * h * dec * 2 * wf);
         ConvOut o4;
-        o4.out16 = v16, o4.res32 = out32, o4.split16 = spf;
+        o4.out16 = v16, o4.res32 = out32, o4.split16 = spf, o4.triple16 = fused;
         conv(ctx, t2_r16, B, h, h, dec, fw.resnet2.w[1], dec, 3, 1, fw.resnet2.b[1], o4, s);
+        if (fused) {
+            // out_conv(deconv(v)) as ONE launch: f32 features of the next level straight from the pixel shuffle
+            const int64_t Mo = (int64_t)B * 4 * h * h;
+            feat32 = (float*)site_buf(ctx, L + ".feat.f32", (size_t)Mo * dec * 4);
+            convt(ctx, v16, B, h, h, dec, fw.fused_w, dec, fw.out_b, feat32, nullptr, false, 0, ACT_NONE, s, false, false,
+                  0, 3);
+            continue;
+        }
         // deconv (levels 1-4) then out_conv 1x1 (+bias)
         const void* pre = v16;
         int ho = h;

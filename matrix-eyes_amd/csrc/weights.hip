@@ -230,6 +230,14 @@ void build_weight_table(me_ctx* ctx) {
     const int64_t k = c.grid / 4;  // 6 for grid 24 (fov.rs:115)
     add_slot(ctx, "fov.head.4.weight", {1, dec / 8, k, k}, PK_CONVK_F32);
     add_slot(ctx, "fov.head.4.bias", {1}, PK_VEC_F32);
+    // derived: out_conv o deconv of fusion levels 1-4 as one ConvTranspose, [4 dec][3 dec] 16-bit each (part of
+    // the arena, so a broadcast carries it; not a checkpoint tensor, so not in the slot table)
+    for (int i = 0; i < 5; ++i) ctx->fused_off[i] = 0;
+    if (ctx->split(SPLIT_FUSION_OUT))
+        for (int i = 1; i < 5; ++i) {
+            ctx->fused_off[i] = ctx->arena_bytes;
+            ctx->arena_bytes = align_up(ctx->arena_bytes + (size_t)(4 * dec) * (3 * dec) * 2, 256);
+        }
 }
 
 void resolve_weights(me_ctx* ctx) {
@@ -262,6 +270,7 @@ void resolve_weights(me_ctx* ctx) {
                 rc[r]->b[k] = fptr(ctx, f + rn[r] + ".residual." + idx[k] + ".bias");
             }
         fw.deconv = i != 0 ? vptr(ctx, f + "deconv.weight") : nullptr;
+        fw.fused_w = ctx->fused_off[i] ? (const void*)(ctx->arena + ctx->fused_off[i]) : nullptr;
         fw.out_w = vptr(ctx, f + "out_conv.weight");
         fw.out_b = fptr(ctx, f + "out_conv.bias");
     }
@@ -303,6 +312,12 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
         data = staged.data();
     }
     const HostSrc src{data, weight_dtype};
+    if (ctx->split(SPLIT_FUSION_OUT) && s.name.rfind("decoder.fusions.", 0) == 0 &&
+        (s.name.find(".deconv.weight") != std::string::npos || s.name.find(".out_conv.weight") != std::string::npos)) {
+        std::vector<float>& keep = ctx->factor_keep[s.name];  // composed at finalize (compose_fusion_out)
+        keep.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) keep[i] = src.get(i);
+    }
     std::vector<char> packed(s.bytes);
     const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
     auto put16 = [&](int64_t dst, int64_t si) {
@@ -393,6 +408,55 @@ void load_checkpoint_pt(me_ctx* ctx, const char* path) {
     finalize_weights(ctx);
 }
 
+// decoder.rs:95-101: `deconv` (ConvTranspose 2x2 stride 2, no bias) then `out_conv` (1x1 + bias) with nothing
+// between them -- one linear map per output position q = (dy, dx): W'_q[co2][ci] = sum_co W_out[co2][co] *
+// W_deconv[ci][co][q].  Composed in f64 from the checkpoint's values and stored as a 16-bit hi + lo pair, so the
+// composed weights are as exact as the activations beside them ([hi | lo | hi] against [W_hi | W_hi | W_lo]).
+// It removes the 4x-resolution intermediate of every fusion level (604 MB written and read back at level 1) and
+// one launch per level.
+static void compose_fusion_out(me_ctx* ctx) {
+    if (!ctx->split(SPLIT_FUSION_OUT)) return;
+    const int64_t D = ctx->cfg.dec_dim;
+    const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
+    auto to16 = [&](float f) { return to_bf16 ? float_to_bf16(f) : float_to_half(f); };
+    auto from16 = [&](uint16_t h) {
+        if (!to_bf16) return half_to_float(h);
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int i = 1; i < 5; ++i) {
+        const std::string f = "decoder.fusions." + std::to_string(i) + ".";
+        auto d = ctx->factor_keep.find(f + "deconv.weight");
+        auto o = ctx->factor_keep.find(f + "out_conv.weight");
+        if (d == ctx->factor_keep.end() || o == ctx->factor_keep.end()) continue;  // finalize reports the missing one
+        const std::vector<float>&Wd = d->second, &Wo = o->second;  // [ci][co][q], [co2][co]
+        std::vector<uint16_t> packed((size_t)(4 * D) * (3 * D));
+        std::vector<double> wq((size_t)D * D), acc((size_t)D);
+        for (int64_t q = 0; q < 4; ++q) {
+            for (int64_t co = 0; co < D; ++co)  // W_deconv for this position as [co][ci]: the inner loops run along ci
+                for (int64_t ci = 0; ci < D; ++ci) wq[co * D + ci] = (double)Wd[(ci * D + co) * 4 + q];
+            for (int64_t co2 = 0; co2 < D; ++co2) {
+                std::fill(acc.begin(), acc.end(), 0.0);
+                for (int64_t co = 0; co < D; ++co) {
+                    const double w = (double)Wo[co2 * D + co];
+                    const double* row = &wq[co * D];
+                    for (int64_t ci = 0; ci < D; ++ci) acc[ci] += w * row[ci];
+                }
+                uint16_t* dst = &packed[(size_t)(q * D + co2) * (3 * D)];
+                for (int64_t ci = 0; ci < D; ++ci) {
+                    const uint16_t hi = to16((float)acc[ci]);
+                    const uint16_t lo = to16((float)(acc[ci] - (double)from16(hi)));
+                    dst[ci] = hi, dst[D + ci] = hi, dst[2 * D + ci] = lo;
+                }
+            }
+        }
+        ME_HIP(hipMemcpy(ctx->arena + ctx->fused_off[i], packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    }
+    // the factors stay (2 MB of host memory): a later me_load_weight of one of them recomposes at the next finalize
+}
+
 // ME_DTYPE_FP8: quantise qkv / proj / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
 // to MX fp8 on the device.  Derived data: a rank that received the arena by broadcast rebuilds it itself.
 void build_fp8_weights(me_ctx* ctx) {
@@ -442,6 +506,7 @@ void finalize_weights(me_ctx* ctx) {
     // LoaderError::RecorderMissing (mod.rs:241-243)
     ME_CHECK(n == 0, ME_ERR_MISSING_WEIGHT, "%d tensors missing from the checkpoint: %s%s", n,
              missing.c_str(), n > 8 ? ", ..." : "");
+    compose_fusion_out(ctx);
     build_fp8_weights(ctx);
     ctx->finalized = true;
 }
