@@ -199,6 +199,15 @@ int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const flo
 /* The same from u8 HWC images, with reconstruction.rs:114-124 fused into the first kernel. */
 int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, const float* f_norm,
                             float* inverse_depth, float* fov_deg_out);
+/* The step as one hipGraph (off by default; ME_GRAPH=1 in the environment turns it on at me_ctx_create).  When
+   on, a me_extract_depth / me_extract_depth_u8 call whose pointers all name device memory, on a context without a
+   progress callback, is enqueued eagerly the first time, captured the second time and replayed with one
+   hipGraphLaunch from its third identical invocation on (the shapes are static per batch size).  New weights,
+   another stream, batch or pointer start over.  Results are bit-identical to eager launches; the GPU is never
+   starved by the host either way, so this buys host CPU time, not depth-maps/s.
+   me_graph_launch_count returns the number of replays so far. */
+int32_t me_ctx_set_graph(me_ctx* ctx, int32_t on);
+int64_t me_graph_launch_count(const me_ctx* ctx);
 
 /* ---- output back end (src/output.rs) -------------------------------------------------- */
 

@@ -90,6 +90,8 @@ extern "C" {
     pub fn me_fov_forward(ctx: *mut MeCtx, x: *const f32, lowres_feature: *const f32, batch: i32, fov_deg: *mut f32) -> i32;
     pub fn me_extract_depth(ctx: *mut MeCtx, img: *const f32, batch: i32, f_norm: *const f32, inverse_depth: *mut f32, fov_deg_out: *mut f32) -> i32;
     pub fn me_extract_depth_u8(ctx: *mut MeCtx, rgb: *const u8, batch: i32, f_norm: *const f32, inverse_depth: *mut f32, fov_deg_out: *mut f32) -> i32;
+    pub fn me_ctx_set_graph(ctx: *mut MeCtx, on: i32) -> i32;
+    pub fn me_graph_launch_count(ctx: *const MeCtx) -> i64;
     pub fn me_depth_clamp_minmax(ctx: *mut MeCtx, depth: *mut f32, count: i64, min_out: *mut f32, max_out: *mut f32) -> i32;
     pub fn me_depth_clamp_minmax_async(ctx: *mut MeCtx, depth: *mut f32, count: i64, minmax_dev: *mut f32) -> i32;
     pub fn me_stereogram(ctx: *mut MeCtx, depth: *const f32, rows: i32, cols: i32, min_depth: f32, max_depth: f32, out_w: i32, out_h: i32, amplitude: f32, noise: *const u8, out: *mut u8) -> i32;

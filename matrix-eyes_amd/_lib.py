@@ -64,6 +64,8 @@ SIGNATURES = {
     "me_fov_forward": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "me_extract_depth": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "me_extract_depth_u8": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "me_ctx_set_graph": (_i32, [_vp, _i32]),
+    "me_graph_launch_count": (_i64, [_vp]),
     "me_depth_clamp_minmax": (_i32, [_vp, _vp, _i64, C.POINTER(_f32), C.POINTER(_f32)]),
     "me_depth_clamp_minmax_async": (_i32, [_vp, _vp, _i64, _vp]),
     "me_stereogram": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp]),

@@ -138,6 +138,7 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
             me_default_config(&ctx->cfg);
         // diagnostic override of me_model_config.split_operands (tools/split_budget.py)
         if (const char* e = getenv("ME_SPLIT_OPERANDS")) ctx->cfg.split_operands = atoi(e);
+        if (const char* e = getenv("ME_GRAPH")) ctx->graph_enabled = atoi(e) != 0;
         validate_config(ctx->cfg);
         ME_CHECK(!ctx->fp8 || ctx->cfg.embed_dim % 256 == 0, ME_ERR_BAD_SHAPE,
                  "ME_DTYPE_FP8 needs embed_dim a multiple of 256 (256x256 tiles, K slabs of 128): %d", ctx->cfg.embed_dim);
@@ -165,6 +166,7 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    ctx->drop_graph();
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -187,6 +189,7 @@ int32_t me_ctx_set_stream(me_ctx* ctx, void* hip_stream) {
     ME_API_BEGIN(ctx)
     ME_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->drop_graph();
     ME_API_END(ctx)
 }
 
@@ -245,6 +248,7 @@ int32_t me_weights_adopt(me_ctx* ctx) {
     for (WeightSlot& s : ctx->slots) s.loaded = true;
     build_fp8_weights(ctx);
     ctx->finalized = true;
+    ctx->drop_graph(), ++ctx->weights_generation;
     ME_API_END(ctx)
 }
 
@@ -473,6 +477,67 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     if (!f_norm && fov_deg_out) finish(ctx, ofov);
     report(ctx, 1.0f, nullptr);
 }
+
+// One step = preprocess (u8 entry) + extract_depth_impl, enqueued on ctx->stream.
+void enqueue_step(me_ctx* ctx, int entry, const void* in_dev, int32_t batch, const float* f_norm,
+                  float* inverse_depth, float* fov_deg_out) {
+    const int S = ctx->S();
+    const float* img_dev = (const float*)in_dev;
+    if (entry == 1) {
+        float* img = (float*)site_buf(ctx, "io.img", (size_t)batch * S * S * 3 * 4);
+        preprocess_u8_launch((const uint8_t*)in_dev, img, batch, S, ctx->stream);
+        img_dev = img;
+    }
+    extract_depth_impl(ctx, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+}
+
+// The step through a hipGraph when nothing in it needs the host: every pointer on the device, no progress
+// callback, no per-kernel timing.  First sight of a key: eager (allocates every site buffer); second: captured
+// and instantiated; later: one hipGraphLaunch.  A capture that cannot complete (a buffer would have to grow, the
+// runtime refuses a call) is discarded and the key stays eager.
+void run_step(me_ctx* ctx, int entry, const void* in_dev, int32_t batch, const float* f_norm,
+              float* inverse_depth, float* fov_deg_out) {
+    const bool eligible = ctx->graph_enabled && !ctx->progress && !profiler().enabled && is_device_ptr(inverse_depth) &&
+                          (!f_norm || is_device_ptr(f_norm)) && (f_norm || !fov_deg_out || is_device_ptr(fov_deg_out));
+    if (!eligible) {
+        enqueue_step(ctx, entry, in_dev, batch, f_norm, inverse_depth, fov_deg_out);
+        return;
+    }
+    me_ctx::GraphKey key;
+    key.in = in_dev, key.f_norm = f_norm, key.depth = inverse_depth, key.fov = f_norm ? nullptr : fov_deg_out;
+    key.stream = ctx->stream, key.batch = batch, key.entry = entry, key.weights_generation = ctx->weights_generation;
+    if (!(ctx->graph_seen && ctx->graph_key == key)) {
+        ctx->drop_graph();
+        ctx->graph_key = key, ctx->graph_seen = true;
+        enqueue_step(ctx, entry, in_dev, batch, f_norm, inverse_depth, fov_deg_out);
+        return;
+    }
+    if (!ctx->graph_exec && !ctx->graph_refused) {
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            ctx->capturing = true;
+            try {
+                enqueue_step(ctx, entry, in_dev, batch, f_norm, inverse_depth, fov_deg_out);
+            } catch (...) {
+                ok = false;
+            }
+            ctx->capturing = false;
+            if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess) ok = false;
+        }
+        if (ok && graph && hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess)
+            ctx->graph_exec = nullptr;
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (!ctx->graph_exec) ctx->graph_refused = true;
+    }
+    if (ctx->graph_exec) {
+        ME_HIP(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        ++ctx->graph_launches;
+    } else {
+        enqueue_step(ctx, entry, in_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    }
+}
 }  // namespace
 
 int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const float* f_norm,
@@ -482,8 +547,12 @@ int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const flo
     check_batch(batch);
     ME_CHECK(img && inverse_depth, ME_ERR_BAD_ARG, "me_extract_depth: null pointer");
     const int S = ctx->S();
+    const bool in_dev = is_device_ptr(img);
     const float* img_dev = (const float*)to_device(ctx, img, (size_t)batch * 3 * S * S * 4, "io.img");
-    extract_depth_impl(ctx, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    if (in_dev)
+        run_step(ctx, 0, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    else
+        enqueue_step(ctx, 0, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
     ME_API_END(ctx)
 }
 
@@ -495,12 +564,22 @@ int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, cons
     ME_CHECK(rgb && inverse_depth, ME_ERR_BAD_ARG, "me_extract_depth_u8: null pointer");
     const int S = ctx->S();
     const size_t npix = (size_t)batch * S * S;
+    const bool in_dev = is_device_ptr(rgb);
     const void* src = to_device(ctx, rgb, npix * 3, "io.rgb");
-    float* img_dev = (float*)site_buf(ctx, "io.img", npix * 3 * 4);
-    preprocess_u8_launch((const uint8_t*)src, img_dev, batch, S, ctx->stream);
-    extract_depth_impl(ctx, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    if (in_dev)
+        run_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
+    else
+        enqueue_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
     ME_API_END(ctx)
 }
+
+int32_t me_ctx_set_graph(me_ctx* ctx, int32_t on) {
+    if (!ctx) return ME_ERR_BAD_ARG;
+    ctx->graph_enabled = on != 0;
+    if (!on) ctx->drop_graph();
+    return ME_OK;
+}
+int64_t me_graph_launch_count(const me_ctx* ctx) { return ctx ? ctx->graph_launches : 0; }
 
 // ---- output back end ---------------------------------------------------------------------
 int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* min_out,

@@ -29,7 +29,9 @@ bool is_device_ptr(const void* p) {
 void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes) {
     DevBuf& b = ctx->bufs[name];
     if (b.p && b.bytes >= bytes) return b.p;
+    if (ctx->capturing) throw CaptureAbort();  // an allocation would synchronise: the caller runs eagerly instead
     if (b.p) {
+        ctx->drop_graph();  // a captured step may hold the old address
         ME_HIP(hipStreamSynchronize(ctx->stream));
         ME_HIP(hipFree(b.p));
         b.p = nullptr, b.bytes = 0;

@@ -52,6 +52,7 @@ int32_t me_bcast_weights(me_ctx* ctx, const void* id128, int32_t rank, int32_t n
         for (WeightSlot& s : ctx->slots) s.loaded = true;
         build_fp8_weights(ctx);
         ctx->finalized = true;
+        ctx->drop_graph(), ++ctx->weights_generation;
     } catch (const me::Error& e) {
         if (comm) (void)ncclCommAbort(comm);
         ctx->last_error = e.msg;

@@ -509,6 +509,7 @@ void finalize_weights(me_ctx* ctx) {
     compose_fusion_out(ctx);
     build_fp8_weights(ctx);
     ctx->finalized = true;
+    ctx->drop_graph(), ++ctx->weights_generation;
 }
 
 }  // namespace me

@@ -82,6 +82,15 @@ class Context:
     def synchronize(self):
         self._check(self.lib.me_ctx_synchronize(self._h))
 
+    def set_graph(self, on: bool = True):
+        """Run device-pointer extract_depth calls as one captured hipGraph (matrix_eyes_hip.h me_ctx_set_graph)."""
+        self._check(self.lib.me_ctx_set_graph(self._h, 1 if on else 0))
+
+    @property
+    def graph_launch_count(self) -> int:
+        """extract_depth calls replayed from the captured hipGraph so far (matrix_eyes_hip.h)."""
+        return int(self.lib.me_graph_launch_count(self._h))
+
     def set_stream(self, hip_stream: Optional[int]):
         self._check(self.lib.me_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
@@ -259,7 +268,11 @@ class Context:
         B = img.shape[0]
         p, keep = _in_ptr(img, np.uint8 if is_u8 else np.float32)
         fn_ptr, fn_keep = C.c_void_p(0), None
-        if f_norm is not None:
+        if f_norm is not None and _is_torch(f_norm) and f_norm.is_cuda:
+            # [B] f32 on the device: nothing in the call touches the host (eligible for the captured graph)
+            fn_keep = f_norm.float().contiguous().reshape(B)
+            fn_ptr = C.c_void_p(fn_keep.data_ptr())
+        elif f_norm is not None:
             fn_keep = np.ascontiguousarray(np.broadcast_to(np.asarray(f_norm, np.float32), (B,)))
             fn_ptr = C.c_void_p(fn_keep.ctypes.data)
         po, out = _out(out, (B, S, S))

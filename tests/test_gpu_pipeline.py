@@ -120,6 +120,56 @@ def test_device_pointers_and_determinism():
     assert np.array_equal(out1.cpu().numpy(), host)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "fp8"])
+def test_captured_graph_replays_the_eager_step(dtype):
+    """A call with device pointers only is eager, then captured, then one hipGraphLaunch (matrix_eyes_hip.h
+    me_graph_launch_count): every replay is bit-identical to the eager result, with the FOV head and with a
+    device-resident f_norm; another output pointer, a host pointer or a progress callback run eagerly."""
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint
+    cfg = m.ModelConfig(grid=8, embed_dim=256, num_heads=4, depth=4, tap_blocks=(1, 2), enc_dims=(64, 128, 128, 128),
+                        dec_dim=256, head_dims=(32, 1))
+    ctx = m.Context(0, dtype, cfg)
+    ctx.load_state_dict(synthetic_checkpoint(cfg))
+    ctx.set_graph(True)
+    S = cfg.img_size
+    structured = torch.from_numpy(synthetic_images(2, S)).cuda()
+    noise = torch.from_numpy(synthetic_images(2, S, "noise")).cuda()
+    rgb = structured.clone()
+    out = torch.empty(2, S, S, dtype=torch.float32, device="cuda")
+    for f_norm in (None, torch.tensor([0.8, 1.3], device="cuda")):
+        rgb.copy_(structured)
+        n0 = ctx.graph_launch_count
+        ctx.extract_depth(rgb, f_norm, out=out)              # first sight of this call: eager
+        ctx.synchronize()
+        eager = out.clone()
+        assert ctx.graph_launch_count == n0
+        for i in range(3):                                   # captured and launched, then replayed
+            out.zero_()
+            ctx.extract_depth(rgb, f_norm, out=out)
+            ctx.synchronize()
+            assert ctx.graph_launch_count == n0 + i + 1
+            assert torch.equal(out, eager)
+        rgb.copy_(noise)                                     # same pointers, new pixels: the graph reads them
+        ctx.extract_depth(rgb, f_norm, out=out)
+        ctx.synchronize()
+        assert ctx.graph_launch_count == n0 + 4 and not torch.equal(out, eager)
+        other = torch.empty_like(out)
+        ctx.extract_depth(rgb, f_norm, out=other)            # another output pointer: eager again
+        ctx.synchronize()
+        assert ctx.graph_launch_count == n0 + 4 and torch.equal(other, out)
+        host = ctx.extract_depth(noise.cpu().numpy(), None if f_norm is None else f_norm.cpu().numpy())
+        assert np.array_equal(host, out.cpu().numpy())       # host pointers: eager, same bits
+    n0 = ctx.graph_launch_count
+    seen = []
+    ctx.set_progress(lambda pos, msg: seen.append(pos))
+    for _ in range(3):
+        ctx.extract_depth(rgb, None, out=other)
+    ctx.set_progress(None)
+    ctx.synchronize()
+    assert ctx.graph_launch_count == n0 and seen
+    ctx.close()
+
+
 def test_state_dict_with_extra_keys_loads_like_the_reference(tmp_path):
     """mod.rs:236-243 checks `result.errors` and `result.missing` only: keys the model does not use (wrapper
     siblings, EMA copies, integer buffers, bf16 tensors) are normal.  Both loaders skip and list them; the depth
