@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         T* __restrict__ y16, float* __restrict__ y32,
                                                         int64_t rows, float eps, RowSegs segs) {
     constexpr int DIM = NPL * 64;
-    constexpr int V = (NPL % 4 == 0) ? 4 : 1;  // elements per access
+    // elements per lane per pass: 8 where the row allows it, so that the 16-bit result leaves as ONE 16-byte
+    // store per lane (8-byte stores run at less than half the rate: the GEMM epilogue's finding, gemm_core.h)
+    constexpr int V = (NPL % 8 == 0) ? 8 : ((NPL % 4 == 0) ? 4 : 1);
     constexpr int NA = NPL / V;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -44,9 +46,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int e = (i * 64 + lane) * V;
-        if constexpr (V == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + e);
-            v[i * 4 + 0] = t.x, v[i * 4 + 1] = t.y, v[i * 4 + 2] = t.z, v[i * 4 + 3] = t.w;
+        if constexpr (V >= 4) {
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + e + 4 * h);
+                v[i * V + 4 * h + 0] = t.x, v[i * V + 4 * h + 1] = t.y, v[i * V + 4 * h + 2] = t.z,
+                                  v[i * V + 4 * h + 3] = t.w;
+            }
         } else {
             v[i] = xr[e];
         }
@@ -66,19 +72,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int e = (i * 64 + lane) * V;
-        if constexpr (V == 4) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + e);
-            const float4 bv = *reinterpret_cast<const float4*>(b + e);
-            const float o0 = (v[i * 4 + 0] - mean) * rstd * wv.x + bv.x;
-            const float o1 = (v[i * 4 + 1] - mean) * rstd * wv.y + bv.y;
-            const float o2 = (v[i * 4 + 2] - mean) * rstd * wv.z + bv.z;
-            const float o3 = (v[i * 4 + 3] - mean) * rstd * wv.w + bv.w;
-            if (y16) {
-                typename Vec16<T>::v4 o;
-                o[0] = (T)o0, o[1] = (T)o1, o[2] = (T)o2, o[3] = (T)o3;
-                *reinterpret_cast<typename Vec16<T>::v4*>(y16 + row * DIM + e) = o;
+        if constexpr (V >= 4) {
+            float o[V];
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + e + 4 * h);
+                const float4 bv = *reinterpret_cast<const float4*>(b + e + 4 * h);
+                o[4 * h + 0] = (v[i * V + 4 * h + 0] - mean) * rstd * wv.x + bv.x;
+                o[4 * h + 1] = (v[i * V + 4 * h + 1] - mean) * rstd * wv.y + bv.y;
+                o[4 * h + 2] = (v[i * V + 4 * h + 2] - mean) * rstd * wv.z + bv.z;
+                o[4 * h + 3] = (v[i * V + 4 * h + 3] - mean) * rstd * wv.w + bv.w;
             }
-            if (y32) *reinterpret_cast<float4*>(y32 + row * DIM + e) = make_float4(o0, o1, o2, o3);
+            if (y16) {
+                typedef T vec __attribute__((ext_vector_type(V)));
+                vec ov;
+#pragma unroll
+                for (int j = 0; j < V; ++j) ov[j] = (T)o[j];
+                *reinterpret_cast<vec*>(y16 + row * DIM + e) = ov;
+            }
+            if (y32) {
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h)
+                    *reinterpret_cast<float4*>(y32 + row * DIM + e + 4 * h) =
+                        make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
+            }
         } else {
             const float o0 = (v[i] - mean) * rstd * w[e] + b[e];
             if (y16) y16[row * DIM + e] = (T)o0;

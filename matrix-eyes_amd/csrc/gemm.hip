@@ -57,8 +57,8 @@ ProfScope::~ProfScope() {
 
 // Tile configurations (the ids are what me_op_* take as tile_cfg)
 static const char* kCfgNames[] = {"256x256x64/8w-pp", "128x128x64/4w", "64x64x64/4w", "160x128x64/4w",
-                                  "64x64x64/4w-ring6"};
-enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_COUNT = 5 };
+                                  "64x64x64/4w-ring6", "192x256x64/8w-pp"};
+enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_PP192 = 5, CFG_COUNT = 6 };
 int gemm_num_configs() { return CFG_COUNT; }
 const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < CFG_COUNT ? kCfgNames[cfg] : "?"; }
 
@@ -74,7 +74,7 @@ static bool dynamic_tile_order() {
     return on;
 }
 
-static int pick_config(int64_t M, int64_t N, int64_t K, int64_t seg1, int64_t seg2) {
+static int pick_config(int64_t M, int64_t N, int64_t K, int64_t seg1, int64_t seg2, bool resid) {
     const int64_t t1 = cdiv(M, 128) * cdiv(N, 128);
     if (N < 128 || t1 < 256) {
         // few 64x64 tiles and a long K (the M = 577 fc2: 160 tiles x 64 slabs): the six-slot ring keeps
@@ -86,11 +86,20 @@ static int pick_config(int64_t M, int64_t N, int64_t K, int64_t seg1, int64_t se
         int cfg, bm, bn, per_cu;
         double eff;
     };
-    static const Cand cands[] = {{CFG_PP256, 256, 256, 1, 1.0}, {CFG_160, 160, 128, 2, 0.80}, {CFG_128, 128, 128, 2, 0.76}};
+    // 192x256 (residual epilogue only): at M = 21760, N = 1024 it turns 340 tiles (1.33 rounds of 256) into 432 (1.69
+    // rounds).  Measured standalone: proj (K = 1024) 94.7 -> 80.3 us, fc2 (K = 4096) 229 -> 252 us -- the shorter
+    // tile moves 17 % more operand bytes per MFMA through L2 -> LDS and a K = 4096 main loop pays for that, a
+    // K = 1024 one is half epilogue and gains from the rounds.
+    const Cand cands[] = {{CFG_PP256, 256, 256, 1, 1.0},
+                          {CFG_PP192, 192, 256, 1, K <= 1024 ? 0.88 : 0.68},
+                          {CFG_160, 160, 128, 2, 0.80},
+                          {CFG_128, 128, 128, 2, 0.76}};
     int best = CFG_128;
     double best_cost = 0.0;
     for (const Cand& c : cands) {
-        if (N < c.bn || (c.cfg == CFG_PP256 && K < 128)) continue;
+        static const bool no_pp192 = getenv("ME_GEMM_NO_PP192") != nullptr;  // diagnostic: A/B on one box
+        if (c.cfg == CFG_PP192 && (!resid || no_pp192)) continue;
+        if (N < c.bn || ((c.cfg == CFG_PP256 || c.cfg == CFG_PP192) && K < 128)) continue;
         if (seg1 % c.bm || seg2 % c.bm) continue;  // row segments must start on tile boundaries
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         // static order: whole rounds; dynamic order: workgroups draw tiles until none are left, so the
@@ -163,10 +172,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
-    int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K, p.seg1, p.seg2);
-    if (cfg == CFG_PP256 && p.K < 128) cfg = CFG_128;  // the two-group kernel prefetches two slabs ahead
+    int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K, p.seg1, p.seg2, amode == A_PLAIN && epi == EPI_RESID_SCALE);
+    if ((cfg == CFG_PP256 || cfg == CFG_PP192) && p.K < 128) cfg = CFG_128;  // the two-group kernel prefetches two slabs ahead
     {
-        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64};
+        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64, 192};
         const int bm = epi == EPI_HEAD_FINAL ? 256 : kTileRows[cfg];
         ME_CHECK(p.seg1 % bm == 0 && p.seg2 % bm == 0 && (p.seg2 == 0 || p.seg2 > p.seg1), ME_ERR_BAD_ARG,
                  "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);

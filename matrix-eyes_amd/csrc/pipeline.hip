@@ -350,9 +350,12 @@ struct MergedVit {
         p.res32 = tok, p.out32 = tok, p.ldc = C;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = bb1, p.gamma_s1 = g1;
         p.W_s2 = w2, p.bias_s2 = bb2, p.gamma_s2 = g2;
-        // tile configuration 0 = the two-group 256x256 kernel (the cost model rates 128x128 a hair cheaper
-        // here; measured it is not)
-        gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, C >= 256 && K >= 128 ? 0 : -1);
+        // the two-group kernel (the cost model rates 128x128 a hair cheaper here; measured it is not): 192-row
+        // tiles for the short K of proj, 256-row tiles for fc2 (gemm.hip pick_config has the measurements)
+        static const bool no_pp192 = getenv("ME_GEMM_NO_PP192") != nullptr;
+        const bool pp = C >= 256 && K >= 128;
+        const bool pp192 = pp && K <= 1024 && !no_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
+        gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, pp192 ? 5 : (pp ? 0 : -1));
     }
 
     // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales

@@ -99,6 +99,8 @@ def test_linear_random_shapes():
         N = 4 * rnd.choice([1, 2, 3, 7, 8, 15, 16, 31, 33, 64, 65, rnd.randrange(1, 160)])
         K = 64 * rnd.choice([1, 2, 3, 4, 5, 9, 16])
         cfg = rnd.randrange(-1, ncfg)
+        if cfg == 5 and it % 3 != 2:
+            cfg = 0                          # the 192x256 two-group tile exists for the residual epilogue only
         g = torch.Generator().manual_seed(it)
         a = dev16(torch.randn(M, K, generator=g), "f16")
         w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), "f16")
@@ -158,7 +160,7 @@ def test_dynamic_tile_order_in_a_child_process():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_linear_residual(dtype, cfg):
     M, N, K = 1154, 256, 512
     ctx = ctx_for("tiny", dtype)
