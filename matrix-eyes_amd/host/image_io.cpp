@@ -63,8 +63,9 @@ RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path, s
     }
     if (!width || !height || ctype < 0) throw ImageError(path + ": no IHDR");
     if ((int64_t)width * height > kMaxPixels) throw ImageError(path + ": PNG larger than 2^28 pixels");
-    if (interlace) throw ImageError(path + ": interlaced PNG is not supported");
-    if (depth != 8 && depth != 16) throw ImageError(path + ": PNG bit depth " + std::to_string(depth) + " is not supported");
+    if (interlace > 1) throw ImageError(path + ": bad PNG interlace method");
+    if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)
+        throw ImageError(path + ": bad PNG bit depth " + std::to_string(depth));
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -74,50 +75,88 @@ RgbImage decode_png(const std::vector<uint8_t>& file, const std::string& path, s
         case 6: channels = 4; break;
         default: throw ImageError(path + ": bad PNG colour type");
     }
-    if (ctype == 3 && depth != 8) throw ImageError(path + ": palette PNG must be 8-bit here");
-    const size_t bpp = (size_t)channels * depth / 8, stride = (size_t)width * bpp;
-    std::vector<uint8_t> raw((stride + 1) * height);
+    // PNG spec table 11.1: sub-byte depths for grey and palette only, 16 bit not for palette
+    if ((depth < 8 && ctype != 0 && ctype != 3) || (depth == 16 && ctype == 3))
+        throw ImageError(path + ": PNG bit depth " + std::to_string(depth) + " does not go with colour type " +
+                         std::to_string(ctype));
+    const size_t bits_pp = (size_t)channels * depth;
+    const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;  // the filters' "corresponding byte" distance
+    auto row_bytes = [&](uint32_t w) { return ((size_t)w * bits_pp + 7) / 8; };
+    // Adam7 passes (x0, y0, dx, dy); a non-interlaced image is one pass over every pixel
+    static const int kAdam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4},
+                                     {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const int kWhole[1][4] = {{0, 0, 1, 1}};
+    const int (*passes)[4] = interlace ? kAdam7 : kWhole;
+    const int npass = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int ps = 0; ps < npass; ++ps) {
+        const uint32_t pw = (width + passes[ps][2] - 1 - passes[ps][0]) / passes[ps][2];
+        const uint32_t ph = (height + passes[ps][3] - 1 - passes[ps][1]) / passes[ps][3];
+        if (pw && ph) total += (row_bytes(pw) + 1) * ph;
+    }
+    std::vector<uint8_t> raw(total);
     uLongf raw_len = raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), idat.size()) != Z_OK || raw_len != raw.size())
         throw ImageError(path + ": PNG data does not inflate to the image size");
-    // undo the scanline filters in place
-    std::vector<uint8_t> prev(stride, 0);
     RgbImage img(width, height);
-    for (uint32_t y = 0; y < height; ++y) {
-        uint8_t* row = &raw[y * (stride + 1) + 1];
-        const int filter = row[-1];
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? row[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = row[i];
-            switch (filter) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) / 2; break;
-                case 4: v += paeth(a, b, c); break;
-                default: throw ImageError(path + ": bad PNG filter");
+    // samples -> 8 bit the way the reference's decoder stack does: grey of 1 / 2 / 4 bits scaled to the full
+    // range (x255, x85, x17), 16-bit samples rounded ((v + 128) / 257), alpha dropped (into_rgb8)
+    const int grey_scale = depth < 8 ? 255 / ((1 << depth) - 1) : 1;
+    auto sample8 = [&](const uint8_t* row, uint32_t x, int c) -> int {  // channel c of pixel x, depth >= 8
+        if (depth == 8) return row[(size_t)x * channels + c];
+        const uint8_t* p = row + ((size_t)x * channels + c) * 2;
+        return (((int)p[0] << 8 | p[1]) + 128) / 257;
+    };
+    auto packed = [&](const uint8_t* row, uint32_t x) -> int {  // depth < 8: one channel, big-endian bit order
+        const size_t bit = (size_t)x * depth;
+        return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+    };
+    size_t off = 0;
+    for (int ps = 0; ps < npass; ++ps) {
+        const int x0 = passes[ps][0], y0 = passes[ps][1], dx = passes[ps][2], dy = passes[ps][3];
+        const uint32_t pw = (width + dx - 1 - x0) / dx, ph = (height + dy - 1 - y0) / dy;
+        if (!pw || !ph) continue;
+        const size_t stride = row_bytes(pw);
+        std::vector<uint8_t> prev(stride, 0);
+        for (uint32_t py = 0; py < ph; ++py) {
+            uint8_t* row = &raw[off + py * (stride + 1) + 1];
+            const int filter = row[-1];
+            // undo the scanline filter in place
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? row[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int v = row[i];
+                switch (filter) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) / 2; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: throw ImageError(path + ": bad PNG filter");
+                }
+                row[i] = (uint8_t)v;
             }
-            row[i] = (uint8_t)v;
-        }
-        std::memcpy(prev.data(), row, stride);
-        uint8_t* out = &img.data[(size_t)y * width * 3];
-        const size_t step = depth / 8;  // 16-bit samples: keep the high byte
-        for (uint32_t x = 0; x < width; ++x) {
-            const uint8_t* px = row + x * bpp;
-            switch (ctype) {
-                case 0:
-                case 4: out[0] = out[1] = out[2] = px[0]; break;
-                case 2:
-                case 6: out[0] = px[0], out[1] = px[step], out[2] = px[2 * step]; break;
-                case 3: {
-                    const size_t k = (size_t)px[0] * 3;
-                    if (k + 2 >= plte.size()) throw ImageError(path + ": palette index out of range");
-                    out[0] = plte[k], out[1] = plte[k + 1], out[2] = plte[k + 2];
-                    break;
+            std::memcpy(prev.data(), row, stride);
+            const uint32_t y = y0 + py * dy;
+            for (uint32_t px = 0; px < pw; ++px) {
+                uint8_t* out = &img.data[((size_t)y * width + x0 + (size_t)px * dx) * 3];
+                switch (ctype) {
+                    case 0: out[0] = out[1] = out[2] = (uint8_t)(depth < 8 ? packed(row, px) * grey_scale : sample8(row, px, 0)); break;
+                    case 4: out[0] = out[1] = out[2] = (uint8_t)sample8(row, px, 0); break;
+                    case 2:
+                    case 6:
+                        out[0] = (uint8_t)sample8(row, px, 0), out[1] = (uint8_t)sample8(row, px, 1),
+                        out[2] = (uint8_t)sample8(row, px, 2);
+                        break;
+                    case 3: {
+                        const size_t k = (size_t)(depth < 8 ? packed(row, px) : row[px]) * 3;
+                        if (k + 2 >= plte.size()) throw ImageError(path + ": palette index out of range");
+                        out[0] = plte[k], out[1] = plte[k + 1], out[2] = plte[k + 2];
+                        break;
+                    }
                 }
             }
-            out += 3;
         }
+        off += (stride + 1) * ph;
     }
     return img;
 }

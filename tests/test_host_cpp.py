@@ -112,6 +112,96 @@ def test_png_codec_against_pillow(tmp_path, mode):
     assert np.array_equal(np.asarray(Image.open(dst)), np.asarray(img.convert("RGB")))
 
 
+def _encode_png(samples, depth, ctype, interlace, palette=None, seed=0):
+    """A PNG file of `samples` [h, w, channels] (ints below 2^depth) written pass by pass, scanline by scanline, with
+    filter types 0 / 1 / 2 chosen at random per line -- every bit depth, colour type and Adam7, which Pillow's
+    writer does not produce."""
+    import random
+    import struct
+    import zlib
+    rnd = random.Random(seed)
+    h, w, ch = samples.shape
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def pack(line):                                   # [pw, ch] -> bytes
+        if depth == 16:
+            return b"".join(struct.pack(">H", int(v)) for v in line.reshape(-1))
+        if depth == 8:
+            return bytes(int(v) for v in line.reshape(-1))
+        out, acc, n = bytearray(), 0, 0
+        for v in line.reshape(-1):
+            acc, n = (acc << depth) | int(v), n + depth
+            if n == 8:
+                out.append(acc)
+                acc, n = 0, 0
+        if n:
+            out.append(acc << (8 - n))
+        return bytes(out)
+
+    passes = ([(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+              if interlace else [(0, 0, 1, 1)])
+    raw = bytearray()
+    for x0, y0, dx, dy in passes:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for line in sub:
+            cur = pack(line)
+            f = rnd.choice([0, 1, 2])
+            if f == 0:
+                enc = cur
+            elif f == 1:
+                enc = bytes((cur[i] - (cur[i - bpp] if i >= bpp else 0)) & 255 for i in range(len(cur)))
+            else:
+                enc = bytes((cur[i] - (prev[i] if prev else 0)) & 255 for i in range(len(cur)))
+            raw += bytes([f]) + enc
+            prev = cur
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette.reshape(-1).tolist()))
+    return out + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("interlace", [0, 1])
+@pytest.mark.parametrize("ctype,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (3, 1), (3, 2), (3, 4), (3, 8),
+                                         (2, 8), (2, 16), (4, 8), (4, 16), (6, 8), (6, 16)])
+def test_png_every_depth_colour_type_and_adam7(tmp_path, ctype, depth, interlace):
+    """reconstruction.rs:95-105 decodes through the image crate: every PNG bit depth and colour type, Adam7 too,
+    grey of 1 / 2 / 4 bits scaled to the full range, 16-bit samples rounded to 8 ((v + 128) / 257), alpha dropped."""
+    from PIL import Image
+    rng = np.random.default_rng(100 * ctype + depth + interlace)
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    for (h, w) in [(1, 1), (3, 9), (13, 11), (16, 24)]:
+        palette = rng.integers(0, 256, (1 << depth, 3), dtype=np.uint8) if ctype == 3 else None
+        samples = rng.integers(0, 1 << depth, (h, w, ch))
+        (tmp_path / "in.png").write_bytes(_encode_png(samples, depth, ctype, interlace, palette, seed=h * w))
+        if ctype == 3:
+            want = palette[samples[:, :, 0]]
+        else:
+            v = samples[:, :, :3] if ch >= 3 else np.repeat(samples[:, :, :1], 3, axis=2)
+            want = (v + 128) // 257 if depth == 16 else v * (255 // ((1 << depth) - 1))
+        r = subprocess.run([SELFTEST, "png", str(tmp_path / "in.png"), str(tmp_path / "out.png")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.asarray(Image.open(tmp_path / "out.png"))
+        assert np.array_equal(got, want.astype(np.uint8)), (h, w)
+        if depth <= 8:                                  # Pillow reads the same file to the same pixels
+            assert np.array_equal(np.asarray(Image.open(tmp_path / "in.png").convert("RGB")), want.astype(np.uint8))
+
+
+def test_png_depth_and_colour_type_must_agree(tmp_path):
+    for ctype, depth in [(2, 4), (6, 2), (4, 1), (3, 16), (0, 3)]:
+        (tmp_path / "bad.png").write_bytes(_encode_png(np.zeros((2, 2, {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]), int), 8, ctype, 0,
+                                                       np.zeros((2, 3), np.uint8) if ctype == 3 else None).replace(
+            bytes([8, ctype, 0, 0, 0]), bytes([depth, ctype, 0, 0, 0]), 1))
+        r = subprocess.run([SELFTEST, "png", str(tmp_path / "bad.png"), str(tmp_path / "o.png")], capture_output=True, text=True)
+        assert r.returncode != 0 and "PNG" in r.stderr
+
+
 @pytest.mark.parametrize("size", [(150, 100), (512, 384), (300, 200)])
 def test_lanczos3_against_pillow(tmp_path, size):
     from PIL import Image
