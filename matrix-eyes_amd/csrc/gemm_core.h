@@ -1277,12 +1277,7 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 4: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
-            case 5:                                                                       \
-                if constexpr (AMODE == A_PLAIN && EPI == EPI_RESID_SCALE)                  \
-                    gemm_launch_pp<T, 192, 256, 2, 4, AMODE, EPI>(p, stream);              \
-                else                                                                      \
-                    fail(ME_ERR_BAD_ARG, "gemm: 192x256 tiles exist for the residual epilogue only"); \
-                break;                                                                    \
+            case 5: gemm_launch_pp<T, 192, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

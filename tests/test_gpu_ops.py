@@ -99,8 +99,6 @@ def test_linear_random_shapes():
         N = 4 * rnd.choice([1, 2, 3, 7, 8, 15, 16, 31, 33, 64, 65, rnd.randrange(1, 160)])
         K = 64 * rnd.choice([1, 2, 3, 4, 5, 9, 16])
         cfg = rnd.randrange(-1, ncfg)
-        if cfg == 5 and it % 3 != 2:
-            cfg = 0                          # the 192x256 two-group tile exists for the residual epilogue only
         g = torch.Generator().manual_seed(it)
         a = dev16(torch.randn(M, K, generator=g), "f16")
         w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), "f16")

@@ -9,8 +9,8 @@ ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 lib.me_debug_set_stamps.argtypes = [C.c_void_p]
 M = int(os.environ.get("STAMPS_M", 35 * 577))
-PP = int(os.environ.get("STAMPS_PP_CFG", 0))   # 0 = the two-group 256x256 kernel, 5 = its 192x256 form (residual epilogue only)
-for (N, K, name, cfg) in [(3072, 1024, "qkv", 0), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", 0), (1024, 1024, "proj-resid", PP), (1024, 4096, "fc2-resid", PP)]:
+PP = int(os.environ.get("STAMPS_PP_CFG", 0))   # 0 = the two-group 256x256 kernel, 5 = its 192x256 form
+for (N, K, name, cfg) in [(3072, 1024, "qkv", PP), (1024, 4096, "fc2", 3), (4096, 1024, "fc1", PP), (1024, 1024, "proj-resid", PP), (1024, 4096, "fc2-resid", PP)]:
     a = torch.randn(M, K, device="cuda").half(); w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     bias = torch.randn(N, device="cuda"); out16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")

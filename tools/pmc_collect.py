@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
 DEFAULT = ["qkv:0", "fc1:0", "proj:0", "fc2:0", "conv768:0", "attn:0"]
-CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6"}
+CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6",
+             5: "192x256x64/8w-pp"}
 PROBE_M = 21760   # tools/gemm_probe.py's default rows
 SHAPES = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
 SHAPES8 = {"qkv8": (3072, 1024), "fc1_8": (4096, 1024), "fc2_8": (1024, 4096)}   # MX fp8 operands
