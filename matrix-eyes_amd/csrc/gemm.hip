@@ -97,8 +97,7 @@ static int pick_config(int64_t M, int64_t N, int64_t K, int64_t seg1, int64_t se
     int best = CFG_128;
     double best_cost = 0.0;
     for (const Cand& c : cands) {
-        static const bool no_pp192 = getenv("ME_GEMM_NO_PP192") != nullptr;  // diagnostic: A/B on one box
-        if (c.cfg == CFG_PP192 && (!resid || no_pp192)) continue;
+        if (c.cfg == CFG_PP192 && !resid) continue;
         if (N < c.bn || ((c.cfg == CFG_PP256 || c.cfg == CFG_PP192) && K < 128)) continue;
         if (seg1 % c.bm || seg2 % c.bm) continue;  // row segments must start on tile boundaries
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);

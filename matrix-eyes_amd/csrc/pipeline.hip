@@ -262,12 +262,18 @@ struct VitRun {
 // 26.5 -> 25.5 ms per step, 580 -> 390 launches.
 struct MergedVit {
     me_ctx* ctx;
-    const VitW &v0, &v1, &v2;
-    int W0, W1;        // windows of segment 0 and of each small segment
+    const VitW &v0, &v1, &v2;  // patch encoder, image encoder, FOV encoder
+    // Physical order of the row space: the SMALL segments first -- [image encoder | FOV encoder | patch encoder]
+    // (without the FOV head: [image encoder | patch encoder]).  Every boundary is then a multiple of the small
+    // segments' padded length (768 rows at one image: a multiple of 256 AND of 192, so the 192-row residual tile
+    // can be used), and the one ragged end is the end of the row space, which every kernel clamps anyway.
+    const VitW &p0, &p1, &p2;  // the ViT of physical segment 0, 1, 2 (p2 unused without the FOV head)
+    int W0, W1;        // windows of the patch encoder and of each small ViT
     bool fov;
     VitTaps taps;
     hipStream_t s;
-    int64_t R0, seg1, seg2, Rtot;  // seg2 == 0 without the FOV encoder
+    int64_t R0, seg1, seg2, Rtot;  // rows of the patch encoder; starts of physical segments 1 and 2 (seg2 == 0: two)
+    int64_t row_main, row_img, row_fov;  // first row of each ViT
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
     float* fin32 = nullptr;
@@ -280,13 +286,15 @@ struct MergedVit {
     MergedVit(me_ctx* ctx_, int B, bool fov_, const void* patches_main, const void* patches_img,
               const void* patches_fov, const VitTaps& taps_, hipStream_t s_)
         : ctx(ctx_), v0(ctx_->w.vit[ME_VIT_PATCH_ENCODER]), v1(ctx_->w.vit[ME_VIT_IMAGE_ENCODER]),
-          v2(ctx_->w.vit[ME_VIT_FOV_ENCODER]), W0(35 * B), W1(B), fov(fov_), taps(taps_), s(s_) {
+          v2(ctx_->w.vit[ME_VIT_FOV_ENCODER]), p0(v1), p1(fov_ ? v2 : v0), p2(v0), W0(35 * B), W1(B), fov(fov_),
+          taps(taps_), s(s_) {
         const int C = ctx->C(), T = ctx->T(), P = ctx->P();
         R0 = (int64_t)W0 * T;
-        seg1 = pad256(R0);
         const int64_t side = pad256((int64_t)W1 * T);
-        seg2 = fov ? seg1 + side : 0;
-        Rtot = seg1 + side * (fov ? 2 : 1);
+        seg1 = side;
+        seg2 = fov ? 2 * side : 0;
+        row_img = 0, row_fov = fov ? side : -1, row_main = fov ? 2 * side : side;
+        Rtot = row_main + pad256(R0);
         tok = (float*)site_buf(ctx, "vitm.tokens", (size_t)Rtot * C * 4);
         xn = (char*)site_buf(ctx, "vitm.xn", (size_t)Rtot * C * 2);
         qkv = (char*)site_buf(ctx, "vitm.qkv", (size_t)Rtot * 3 * C * 2);
@@ -299,17 +307,18 @@ struct MergedVit {
             att_s = (uint8_t*)site_buf(ctx, "vitm.att.scale", (size_t)Rtot * C / 32);
         }
         fin16 = (char*)site_buf(ctx, "vitm.final16", (size_t)Rtot * C * 2);
-        segs.seg1 = seg1, segs.seg2 = seg2, segs.win0 = W0, segs.win1 = W1;
+        // attention: windows of physical segments 0 and 1, the rest belong to the last segment
+        segs.seg1 = seg1, segs.seg2 = seg2, segs.win0 = W1, segs.win1 = fov ? W1 : W0;
         // vit.rs:287-295 per ViT: patch embed + cls + pos into its segment
-        embed(v0, patches_main, W0, 0);
-        embed(v1, patches_img, W1, seg1);
-        if (fov) embed(v2, patches_fov, W1, seg2);
+        embed(v0, patches_main, W0, row_main);
+        embed(v1, patches_img, W1, row_img);
+        if (fov) embed(v2, patches_fov, W1, row_fov);
         // The padding rows of each segment take part in every row-wise kernel of a block (x += gamma * (...),
         // 48 times per call) and the buffer outlives the call: zeroed here, they hold the same finite values on
         // every call instead of growing without bound or keeping another batch size's rows.
-        zero_rows(R0, seg1);
-        zero_rows(seg1 + (int64_t)W1 * T, seg1 + side);
-        if (fov) zero_rows(seg2 + (int64_t)W1 * T, Rtot);
+        zero_rows(row_img + (int64_t)W1 * T, row_img + side);
+        if (fov) zero_rows(row_fov + (int64_t)W1 * T, row_fov + side);
+        zero_rows(row_main + R0, Rtot);
         (void)P;
     }
 
@@ -350,11 +359,13 @@ struct MergedVit {
         p.res32 = tok, p.out32 = tok, p.ldc = C;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = bb1, p.gamma_s1 = g1;
         p.W_s2 = w2, p.bias_s2 = bb2, p.gamma_s2 = g2;
-        // the two-group kernel (the cost model rates 128x128 a hair cheaper here; measured it is not): 192-row
-        // tiles for the short K of proj, 256-row tiles for fc2 (gemm.hip pick_config has the measurements)
-        static const bool no_pp192 = getenv("ME_GEMM_NO_PP192") != nullptr;
+        // the two-group 256x256 kernel (the cost model rates 128x128 a hair cheaper here; measured it is not).  Its
+        // 192-row form (tile config 5; the segment order above makes every boundary a multiple of 192 at one image)
+        // wins for proj stand-alone (94.7 -> 80.3 us) and loses in the step (90 -> 95.6 us per launch, same box,
+        // bench.py A/B): ME_GEMM_PP192=1 selects it for that comparison.
+        static const bool use_pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const bool pp = C >= 256 && K >= 128;
-        const bool pp192 = pp && K <= 1024 && !no_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
+        const bool pp192 = pp && K <= 1024 && use_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, pp192 ? 5 : (pp ? 0 : -1));
     }
 
@@ -385,7 +396,7 @@ struct MergedVit {
 
     // vit.rs:163-170 Block::forward for the three ViTs
     void block(int i) {
-        const VitBlockW &b0 = v0.blocks[i], &b1 = v1.blocks[i], &b2 = v2.blocks[i];
+        const VitBlockW &b0 = p0.blocks[i], &b1 = p1.blocks[i], &b2 = p2.blocks[i];  // by physical segment
         const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
         if (ctx->fp8) {
             // BASELINE configs[3]: LayerNorm writes MX fp8, the four linears run on the scaled fp8 MFMA; attention
@@ -400,7 +411,7 @@ struct MergedVit {
             layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
             gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1);
             gemm8(hid, hid_s, 4 * C, C, b0, b1, b2, 2);
-            if (taps.fn) taps.fn(taps.user, i, tok);
+            if (taps.fn) taps.fn(taps.user, i, tok + row_main * C);
             return;
         }
         set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
@@ -412,18 +423,19 @@ struct MergedVit {
         layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
         gemm_all(xn, C, b0.fc1_w, b1.fc1_w, b2.fc1_w, b0.fc1_b, b1.fc1_b, b2.fc1_b, 4 * C, hid, ACT_GELU);
         resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2);
-        if (taps.fn) taps.fn(taps.user, i, tok);
+        if (taps.fn) taps.fn(taps.user, i, tok + row_main * C);
     }
 
     // vit.rs:343 final norm of each ViT; the 16-bit results of segments 0 / 1 / 2
     // want32: also keep the normalised tokens in f32 (the source of split [hi | lo] token maps)
     void finish(bool want32) {
-        set_ln(v1.norm_w, v1.norm_b, v2.norm_w, v2.norm_b);
+        set_ln(p1.norm_w, p1.norm_b, p2.norm_w, p2.norm_b);
         fin32 = want32 ? (float*)site_buf(ctx, "vitm.final32", (size_t)Rtot * ctx->C() * 4) : nullptr;
-        layernorm_launch(tok, v0.norm_w, v0.norm_b, fin16, fin32, Rtot, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s,
+        layernorm_launch(tok, p0.norm_w, p0.norm_b, fin16, fin32, Rtot, ctx->C(), ctx->cfg.ln_eps, ctx->dtype, s,
                          &segs);
     }
-    int64_t seg_row(int seg) const { return seg == 0 ? 0 : (seg == 1 ? seg1 : seg2); }
+    // seg: 0 = patch encoder, 1 = image encoder, 2 = FOV encoder (the ViT, not the physical position)
+    int64_t seg_row(int seg) const { return seg == 0 ? row_main : (seg == 1 ? row_img : row_fov); }
     void* final16(int seg) const { return fin16 + seg_row(seg) * ctx->C() * 2; }
     const float* final32(int seg) const { return fin32 + seg_row(seg) * ctx->C(); }
 };
