@@ -63,6 +63,10 @@ int32_t me_op_layernorm_fp8(me_ctx* ctx, const float* x32, const float* weight, 
 int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
                          const uint8_t* W8, const uint8_t* w_scale, const float* bias, void* out16, uint8_t* out8,
                          uint8_t* out8_scale, const float* gamma, float* x32);
+/* me_op_attention with the output written as an MX fp8 activation operand (out8 [windows*tokens][heads*64] bytes +
+   block scales; heads even): the bytes me_op_quantize_fp8 gives for me_op_attention's 16-bit output. */
+int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8_t* out8_scale, int32_t windows,
+                            int32_t tokens, int32_t heads);
 /* f32 <-> context 16-bit type */
 int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
 int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "me_op_conv_transpose2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp,
                                        _i32, _i32]),
     "me_op_quantize_fp8": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "me_op_attention_fp8": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32]),
     "me_op_scale_index": (_i64, [_i64, _i32, _i64, _i32]),
     "me_op_layernorm_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
     "me_op_linear_fp8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

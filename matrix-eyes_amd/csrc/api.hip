@@ -796,6 +796,15 @@ int32_t me_op_quantize_fp8(me_ctx* ctx, const void* src16, int64_t rows, int32_t
     ME_API_END(ctx)
 }
 
+int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8_t* out8_scale, int32_t windows,
+                            int32_t tokens, int32_t heads) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(qkv16 && out8 && out8_scale, ME_ERR_BAD_ARG, "me_op_attention_fp8: null pointer");
+    attention_launch(qkv16, nullptr, windows, tokens, heads, ctx->dtype, ctx->stream, nullptr, out8, out8_scale,
+                     cdiv((int64_t)windows * tokens, 128));
+    ME_API_END(ctx)
+}
+
 int64_t me_op_scale_index(int64_t row, int32_t kblock, int64_t rows, int32_t weight_layout) {
     return weight_layout ? w_scale_index(row, kblock, rows / 64) : a_scale_index(row, kblock, cdiv(rows, 128));
 }

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mx_fp8.h"
 
 namespace me {
 
@@ -70,7 +71,9 @@ __device__ unsigned long long* g_att_stamps = nullptr;
 template <typename T, int NSLOT, int MINW>
 __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int tokens, int heads,
-                                                        int ngroups, float scale_log2e, RowSegs segs) {
+                                                        int ngroups, float scale_log2e, RowSegs segs,
+                                                        uint8_t* __restrict__ out8, uint8_t* __restrict__ out8_scale,
+                                                        int64_t out8_mt) {
     typedef typename Mfma32<T>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -329,10 +332,43 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
     }
 
     // ---- normalise and store: lane holds q = q0 + r, d = 32 dblk + 8 (g >> 2) + 4 h + (g & 3)
+    // The product is rounded to f32 and THEN to 16 bit in both output forms: left to itself the compiler fuses
+    // multiply and conversion into one v_fma_mixlo (a single rounding) in one form and not in the other, and the
+    // fp8 form's bytes must be those of the 16-bit form quantised.
+    auto round16 = [](float x) -> T {
+        asm volatile("" : "+v"(x));
+        return (T)x;
+    };
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + r;
-    if (q < tokens) {
+    if (out8) {
+        // ME_DTYPE_FP8: the output leaves as the projection's MX fp8 activation operand (mx_fp8.h).  A 32-column
+        // block of a row is this lane's 16 values of one d-block and lane ^ 32's; values are rounded to 16 bit
+        // first, so the bytes equal those of quantize_f16_to_fp8_launch over the 16-bit output.
+        const int64_t m = row0 + q;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            float v[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                v[e] = (float)round16(o[d][e] * inv);
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const unsigned sb = mx_scale_byte(amax);
+            const float sc = mx_inv_scale(sb);
+            if (q < tokens) {
+                uint8_t* op = out8 + m * C + head * 64 + d * 32 + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<unsigned*>(op + 8 * g4) =
+                        pack_fp8x4(v[4 * g4] * sc, v[4 * g4 + 1] * sc, v[4 * g4 + 2] * sc, v[4 * g4 + 3] * sc);
+                if (h == 0) out8_scale[a_scale_index(m, head * 2 + d, out8_mt)] = (uint8_t)sb;
+            }
+        }
+    } else if (q < tokens) {
         T* op = out + (row0 + q) * C + head * 64 + 4 * h;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
                 typedef T v4 __attribute__((ext_vector_type(4)));
                 v4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (T)(o[d][4 * g4 + e] * inv);
+                for (int e = 0; e < 4; ++e) v[e] = round16(o[d][4 * g4 + e] * inv);
                 *reinterpret_cast<v4*>(op + d * 32 + 8 * g4) = v;
             }
     }
@@ -365,10 +401,13 @@ extern "C" int32_t me_debug_set_att_stamps(void* dev_ptr) {
 #endif
 
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
-                      int32_t dtype, hipStream_t stream, const RowSegs* segs_opt) {
+                      int32_t dtype, hipStream_t stream, const RowSegs* segs_opt, uint8_t* out8,
+                      uint8_t* out8_scale, int64_t out8_mt) {
     const RowSegs segs = segs_opt ? *segs_opt : RowSegs();
     ME_CHECK(windows > 0 && tokens > 0 && heads > 0, ME_ERR_BAD_SHAPE,
              "attention: windows=%d tokens=%d heads=%d", windows, tokens, heads);
+    ME_CHECK(!out8 || (out8_scale && out8_mt > 0 && heads % 2 == 0), ME_ERR_BAD_ARG,
+             "attention: fp8 output needs its scale buffer and K = 64 heads a multiple of 128");
     ME_CHECK((int64_t)windows * heads * ((tokens + 127) / 128) < (1ll << 30), ME_ERR_BAD_SHAPE,
              "attention: grid too large");
     const int nqb = (tokens + 127) / 128, ngroups = windows * heads;
@@ -378,10 +417,10 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == ME_DTYPE_F16)
         hipLaunchKernelGGL((attention_kernel<f16, 2, 4>), grid, dim3(256), 0, stream, (const f16*)qkv,
-                           (f16*)out, tokens, heads, ngroups, scale_log2e, segs);
+                           (f16*)out, tokens, heads, ngroups, scale_log2e, segs, out8, out8_scale, out8_mt);
     else if (dtype == ME_DTYPE_BF16)
         hipLaunchKernelGGL((attention_kernel<bf16, 2, 4>), grid, dim3(256), 0, stream, (const bf16*)qkv,
-                           (bf16*)out, tokens, heads, ngroups, scale_log2e, segs);
+                           (bf16*)out, tokens, heads, ngroups, scale_log2e, segs, out8, out8_scale, out8_mt);
     else
         fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
     ME_HIP(hipGetLastError());

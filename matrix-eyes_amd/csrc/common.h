@@ -235,8 +235,11 @@ struct RowSegs {
     int32_t win0 = 0, win1 = 0;
     const float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;  // LayerNorm weights of 1 and 2
 };
+// out8 != nullptr: the output is written as MX fp8 bytes [rows][C] + activation-layout block scales (mx_fp8.h,
+// out8_mt = 128-row tiles of the operand) instead of 16-bit `out`
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
-                      int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr);
+                      int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr, uint8_t* out8 = nullptr,
+                      uint8_t* out8_scale = nullptr, int64_t out8_mt = 0);
 
 // ---------------------------------------------------------------------------------------
 // Row-wise and layout kernels (elementwise.hip)

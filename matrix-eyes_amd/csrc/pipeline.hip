@@ -404,8 +404,17 @@ struct MergedVit {
             set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
             layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
             gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
-            attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
-            quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
+            // the attention kernel writes the projection's fp8 operand itself (the bytes a separate
+            // quantize_f16_to_fp8 pass over its 16-bit output would give: ME_FP8_ATT_SEPARATE=1 runs that pass,
+            // the test compares the two)
+            static const bool separate = getenv("ME_FP8_ATT_SEPARATE") != nullptr;
+            if (separate || heads % 2) {
+                attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
+                quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
+            } else {
+                attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs, att8, att_s,
+                                 Rtot / 128);
+            }
             gemm8(att8, att_s, C, C, b0, b1, b2, 3);
             set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
             layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);

@@ -186,3 +186,55 @@ def test_extract_depth_fp8_small_model():
     assert res["f16"][0]["rel_l2"] < 2e-3
     assert res["f16"][0]["rel_l2"] < res["fp8"][0]["rel_l2"] < 0.1
     assert np.abs(res["fp8"][1] - ref_fov.numpy()).max() < 2.0
+
+
+@pytest.mark.parametrize("windows,tokens,heads", [(3, 577, 4), (5, 65, 2), (2, 130, 16), (1, 128, 2)])
+def test_attention_fp8_output_equals_quantised_16bit_output(windows, tokens, heads):
+    ctx = ctx_for("tiny", "f16")
+    C, rows = heads * 64, windows * tokens
+    g = torch.Generator().manual_seed(tokens + heads)
+    qkv = (torch.randn(rows, 3 * C, generator=g) * 1.5).half().cuda()
+    out16 = torch.empty(rows, C, dtype=torch.float16, device="cuda")
+    nsc = (rows + 127) // 128 * 128 * C // 32
+    want8 = torch.zeros(rows, C, dtype=torch.uint8, device="cuda"); want_s = torch.zeros(nsc, dtype=torch.uint8, device="cuda")
+    got8 = torch.zeros_like(want8); got_s = torch.zeros_like(want_s)
+    torch.cuda.synchronize()
+    ctx._check(ctx.lib.me_op_attention(ctx.handle, ptr(qkv), ptr(out16), windows, tokens, heads))
+    ctx._check(ctx.lib.me_op_quantize_fp8(ctx.handle, ptr(out16), rows, C, 0, ptr(want8), ptr(want_s)))
+    ctx._check(ctx.lib.me_op_attention_fp8(ctx.handle, ptr(qkv), ptr(got8), ptr(got_s), windows, tokens, heads))
+    ctx.synchronize()
+    bad = (got8 != want8).nonzero()
+    assert bad.numel() == 0, (bad[:8].tolist(), int((got8 != want8).sum()))
+    assert torch.equal(got_s, want_s)
+
+
+_SEPARATE_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import matrix_eyes_amd as m
+from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+cfg = m.ModelConfig(grid=8, embed_dim=256, num_heads=4, depth=4, tap_blocks=(1, 2), enc_dims=(64, 128, 128, 128),
+                    dec_dim=256, head_dims=(32, 1))
+ctx = m.Context(0, "fp8", cfg)
+ctx.load_state_dict(synthetic_checkpoint(cfg))
+d, fov = ctx.extract_depth(synthetic_images(2, cfg.img_size), None, want_fov=True)
+np.save(sys.argv[2], d)
+"""
+
+
+def test_attention_writes_the_projection_operand_itself(tmp_path):
+    """fp8 contexts: the attention kernel stores its output as MX fp8 bytes + block scales (values rounded to 16 bit
+    first); ME_FP8_ATT_SEPARATE=1 runs the 16-bit store and the stand-alone quantiser instead.  Same depth, bit
+    for bit, with and without the FOV head's third row segment."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("fused", {}), ("separate", {"ME_FP8_ATT_SEPARATE": "1"})):
+        path = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _SEPARATE_CHILD, root, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
