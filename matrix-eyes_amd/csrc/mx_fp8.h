@@ -39,8 +39,9 @@ __device__ __forceinline__ void store_granule_fp8(const GemmParams& p, int m, in
     float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(a[e]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    // lanes l ^ 1 and l ^ 2 by quad-permute DPP (a register move) instead of two ds_bpermute round trips
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0xB1, 0xF, 0xF, true)));
+    amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x4E, 0xF, 0xF, true)));
     const unsigned sb = mx_scale_byte(amax);
     const float inv = mx_inv_scale(sb);
     uint2 v;
