@@ -16,7 +16,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     lib, h = ctx.lib, ctx.handle
-    for (Hh, cin, cout) in [(48, 1024, 1024), (48, 1024, 256), (96, 1024, 256), (96, 512, 512), (96, 256, 256), (192, 256, 256), (24, 1024, 1024)]:
+    for (Hh, cin, cout) in [(48, 1024, 1024), (48, 1024, 256), (96, 1024, 256), (96, 512, 512), (96, 256, 256), (192, 256, 256), (192, 512, 256), (384, 256, 256), (24, 1024, 1024)]:
         xb = torch.randn(1, Hh + 2, Hh + 2, cin, device="cuda").half()
         w = (torch.randn(cout, 9 * cin, device="cuda") / (3 * cin ** 0.5)).half()
         bias = torch.randn(cout, device="cuda")
