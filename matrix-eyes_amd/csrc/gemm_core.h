@@ -1073,7 +1073,11 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
     const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
-    const int64_t grid = ntiles < resident ? ntiles : resident;
+    int64_t grid = ntiles < resident ? ntiles : resident;
+    // diagnostic (tools/dual_stream_probe.py): cap the persistent grid so that two launches on two streams share
+    // the chip instead of the first one taking every CU until it ends
+    static const int grid_limit = getenv("ME_GEMM_GRID_LIMIT") ? atoi(getenv("ME_GEMM_GRID_LIMIT")) : 0;
+    if (grid_limit >= 8 && grid > grid_limit) grid = grid_limit - grid_limit % 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
     ME_HIP(hipGetLastError());
 }
