@@ -57,6 +57,8 @@ def test_no_cpu_fallback(lib):
     assert lib.me_weights_finalize(None) == 1
     assert lib.me_extract_depth(None, None, 1, None, None, None) == 1
     assert lib.me_expected_weight_count(None) == 0
+    assert lib.me_ctx_set_graph(None, 1) == 1 and lib.me_graph_launch_count(None) == 0
+    assert lib.me_load_checkpoint_pt(None, b"x.pt") == 1 and lib.me_unused_weight_count(None) == 0
     lib.me_ctx_destroy(None)
 
 
