@@ -272,7 +272,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             }
         }
         if constexpr (MODE == 3)
-            store_granule_fp8(p, m, n, a);
+            *reinterpret_cast<uint2*>(p.out8 + (int64_t)m * p.ldc + n) = quantise_granule_fp8(p, m, n, a);
         else
             store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
     } else if constexpr (EPI == EPI_STORE) {
@@ -482,6 +482,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     const char* src = epi_lds + rr * RS;
                     v[it][0] = *reinterpret_cast<const f32x4*>(src + (((2 * gc) ^ rr) & CMASK) * 16);
                     v[it][1] = *reinterpret_cast<const f32x4*>(src + (((2 * gc + 1) ^ rr) & CMASK) * 16);
+                }
+                if constexpr (MODE == 3) {
+                    // fp8 output (M, N multiples of 256: every row and column exists): two rows at a time, so that
+                    // each lane's bytes leave as one 16-byte store
+                    static_assert(ITERS % 2 == 0, "row pairs");
+#pragma unroll
+                    for (int it = 0; it < ITERS; it += 2) {
+                        uint2 q[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            float a[8];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x4 g = gelu_erf4(f32x4{v[it + u][h][0] + lc.bias[h].x, v[it + u][h][1] + lc.bias[h].y,
+                                                                v[it + u][h][2] + lc.bias[h].z, v[it + u][h][3] + lc.bias[h].w});
+                                a[4 * h] = g[0], a[4 * h + 1] = g[1], a[4 * h + 2] = g[2], a[4 * h + 3] = g[3];
+                            }
+                            q[u] = quantise_granule_fp8(p, row.m + u * RPI, n, a);
+                        }
+                        store_granule_pair_fp8(p, row.m, row.m + RPI, n, q[0], q[1]);
+                        row.m += 2 * RPI;
+                    }
+                    continue;
                 }
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
