@@ -1,5 +1,6 @@
 set -e
-for op in proj fc2; do for cfg in 0 5; do
+# proj / fc2 stand-alone at M = 21760: usage  [ME_GEMM_AG1=2] bash tools/probe_resid.sh "0 5"
+for op in proj fc2; do for cfg in ${1:-0 5}; do
 python - <<P
 import sys, os, ctypes as C, math, torch
 sys.path.insert(0, os.getcwd())
@@ -17,6 +18,6 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(50): f()
 e1.record(); e1.synchronize()
 ms = e0.elapsed_time(e1) / 50
-print("$op cfg $cfg: %.1f us  %.0f TFLOP/s" % (ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+print("$op cfg $cfg AG1=%s: %.1f us  %.0f TFLOP/s" % (os.environ.get("ME_GEMM_AG1", "0"), ms * 1e3, 2.0 * M * N * K / ms / 1e9))
 P
 done; done
