@@ -4,7 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A step = one pass of the hot path (me_extract_depth_u8: preprocess ->
+One process per GPU.  Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the script starts its N
+ranks itself, as child processes created BEFORE anything touches the GPU, each with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set, waits for them and exits with their worst code; under
+torch.distributed.run it is one of the ranks.  A step = one pass of the hot path (me_extract_depth_u8: preprocess ->
 encoder -> decoder -> FOV head -> depth head) over one batch of synthetic u8 images that already sit
 in HBM.  At N = 1 the workload is BASELINE.json configs[1] (a single 1536x1536 image, depth map +
 FOV head).  With N > 1 every rank runs the same per-GPU batch on its own images (weak scaling, image
@@ -83,9 +86,47 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (me_ctx_set_graph); default: eager launches, "
                          "measured equal (f16) to 1 %% faster (fp8): the GPU is never starved by the host")
-    ap.add_argument("--cpu-windows", type=int, default=1,
-                    help="ViT windows of the oracle sample timed for cpu_baseline")
+    ap.add_argument("--cpu-windows", type=int, default=0,
+                    help="cpu_baseline all-cores leg: 0 (default) = the oracle's WHOLE path on one 1536x1536 image, timed "
+                         "once (about 75 s on a 128-thread host); n > 0 = a bounded sample of n ViT windows scaled by "
+                         "FLOP share (quick runs)")
+    ap.add_argument("--chain", action="store_true",
+                    help="BASELINE configs[4]: time depth -> DepthMap::new (clamp + range) -> stereogram -> textured OBJ per "
+                         "image instead of the depth step alone; reports images/s with the OBJ leg split out")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N child processes, one per GPU, over RCCL.  This process has
+    not imported torch or touched the GPU (a process that has must never be replaced or forked from); the children
+    are plain `python bench.py ...` commands with the rank environment torch.distributed.run would give them.  Rank
+    0 prints the JSON line on this process's stdout; a rank that fails ends the others."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for o in pending:              # the others would wait for this rank in a collective for ever
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return worst
 
 
 def cpu_baseline(cfg, weights, windows):
@@ -117,10 +158,25 @@ def cpu_baseline(cfg, weights, windows):
                            f"thread(s); scaled by that share")}, dt
 
     all_threads = torch.get_num_threads()
-    multi, dt = sample(windows, all_threads)
-    if dt < 6.0:      # aim at about 10 s of CPU work per sample
-        multi, dt = sample(int(min(35, max(windows + 1, round(windows * 10.0 / dt)))), all_threads)
-    single, _ = sample(3, 1)          # three windows = 1146 GFLOP: ~10 s at one core's sgemm rate
+    if windows <= 0:
+        # the whole path, once: preprocess -> encoder (35 + 1 windows) -> decoder -> FOV head -> depth head on one
+        # 1536x1536 image -- nothing scaled.  (A few-window sample scaled by FLOP share read 2x too slow: 128 threads
+        # barely beat one on 577-row problems, the batched 35-window pass is what the oracle really runs.)
+        from matrix_eyes_amd.synthetic import synthetic_images
+        img = O.preprocess_u8(synthetic_images(1, cfg.img_size, "structured", seed=4321))
+        torch.set_num_threads(all_threads)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.extract_depth(img, None, weights, ocfg)
+            dt = time.perf_counter() - t0
+        multi = {"value": 1.0 / dt, "cores": all_threads,
+                 "sample": (f"the whole path on ONE 1536x1536 image (FOV head on, {TFLOP_PER_IMAGE_FOV} TFLOP), timed once: "
+                            f"{dt:.1f} s on {all_threads} thread(s); nothing scaled")}
+    else:
+        multi, dt = sample(windows, all_threads)
+        if dt < 6.0:      # aim at about 10 s of CPU work per sample
+            multi, dt = sample(int(min(35, max(windows + 1, round(windows * 10.0 / dt)))), all_threads)
+    single, _ = sample(3, 1)          # three windows = 1146 GFLOP: ~10 s at one core's sgemm rate (scaled by share)
     torch.set_num_threads(all_threads)
     return {
         "value": multi["value"],
@@ -135,6 +191,8 @@ def cpu_baseline(cfg, weights, windows):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -144,9 +202,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes "
-                         f"(WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` plainly (it starts "
+                         f"its ranks itself) or under torch.distributed.run with --nproc-per-node N")
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -186,11 +244,42 @@ def main():
     depth = torch.empty(B, S, S, dtype=torch.float32, device="cuda")
     f_norm = torch.ones(B, device="cuda") if args.no_fov else None   # on the device: no host pointer in the call
 
+    chain_ms = {"depth": 0.0, "raster": 0.0, "obj": 0.0, "obj_bytes": 0}
+    if args.chain:
+        # BASELINE configs[4] per image: depth -> DepthMap::new (clamp + range, output.rs:44-75) -> stereogram
+        # (output.rs:141-193) -> textured OBJ + MTL (output.rs:195-261) written to a file on tmpfs
+        import shutil
+        import tempfile
+        out_dir = tempfile.mkdtemp(prefix=f"me_chain_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        noise = torch.from_numpy(np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)).cuda()
+        stereo = torch.empty(B, S, S, 3, dtype=torch.uint8, device="cuda")
+
     def step():
+        if not args.chain:
+            ctx.extract_depth(rgb, f_norm, out=depth)
+            return
+        t0 = time.perf_counter()
         ctx.extract_depth(rgb, f_norm, out=depth)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        maps = [m.DeviceDepthMap(ctx, depth[b], (S, S)) for b in range(B)]
+        for b in range(B):
+            maps[b].stereogram(1.0 / 16.0, noise, out=stereo[b])
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        for b in range(B):
+            path = os.path.join(out_dir, f"mesh{b}.obj")
+            maps[b].output_mesh(path, "photo.jpg", m.VertexMode.Texture)
+            chain_ms["obj_bytes"] = os.path.getsize(path)
+        t3 = time.perf_counter()
+        chain_ms["depth"] += (t1 - t0) * 1e3
+        chain_ms["raster"] += (t2 - t1) * 1e3
+        chain_ms["obj"] += (t3 - t2) * 1e3
 
     for _ in range(args.warmup):
         step()
+    for k in ("depth", "raster", "obj"):
+        chain_ms[k] = 0.0
 
     def fence():
         torch.cuda.synchronize()
@@ -204,6 +293,13 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    my_step_ms = elapsed / args.steps * 1e3
+    chain_report = {k: (v / (args.steps * B) if k != "obj_bytes" else v) for k, v in chain_ms.items()}
+    if args.chain:
+        shutil.rmtree(out_dir, ignore_errors=True)
+        args_chain, args.chain = True, False      # the roofline / end-to-end legs below time the depth step itself
+    else:
+        args_chain = False
     graph_replays = ctx.graph_launch_count
     # roofline leg: the same steps once more with every GEMM / attention / LayerNorm launch bracketed
     # by HIP events on the launch stream (an event costs ~5 us of queue time, so it is kept out of the
@@ -224,11 +320,15 @@ def main():
         for _ in range(n_e2e):
             ctx.extract_depth(rgb_host, f_norm)
         e2e_ms = (time.perf_counter() - t1) / n_e2e * 1e3
+    per_rank_ms = [my_step_ms]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, my_step_ms)
     assert bool(torch.isfinite(depth).all()), "non-finite depth"
+    assert ctx.status_flags() == 0, "an f16 operand overflowed during the benchmark (me_status_flags)"
 
     if rank == 0:
         images = world * B * args.steps
@@ -272,6 +372,10 @@ def main():
                                f"broadcast at start-up ({t_load:.1f} s incl. synthetic init)",
                 "end_to_end": "end_to_end_ms_per_step: u8 image in pageable host memory in, f32 depth in host memory out "
                               "(H2D 7.1 MB + D2H 9.4 MB per image and their synchronisation included), rank 0",
+                "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
+                "weights_broadcast": ("none (one rank)" if world == 1 else
+                                      ("me_bcast_weights: the library's own RCCL communicator" if os.environ.get("ME_NATIVE_RCCL") == "1"
+                                       else f"torch.distributed broadcast of the arena tensor (backend {backend})")),
                 "split_operands": cfg.split_operands,
                 "launch": (f"one hipGraphLaunch per step ({graph_replays} replays up to the end of the timed region)"
                            if graph_replays else "eager: one launch per kernel"),
@@ -299,6 +403,16 @@ def main():
                          "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1) if k["flops"] else None}
                         for k in kernels[:8]],
         }
+        if args_chain:
+            # configs[4]: `value` is whole-chain images/s; the legs are per image, host wall clock around synchronised
+            # sections (depth = the model step, raster = DepthMap::new + stereogram kernels, obj = mesh index +
+            # vertex kernels + text formatting + file write on tmpfs)
+            out["config"]["workload"] = (f"BASELINE.json configs[4] per GPU: {B} image(s) per step, depth -> DepthMap::new -> "
+                                         "stereogram -> textured OBJ + MTL on tmpfs")
+            out["chain"] = {"depth_ms_per_image": round(chain_report["depth"], 3),
+                            "raster_ms_per_image": round(chain_report["raster"], 3),
+                            "obj_ms_per_image": round(chain_report["obj"], 3),
+                            "obj_bytes": chain_report["obj_bytes"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_windows)
         print(json.dumps(out), flush=True)

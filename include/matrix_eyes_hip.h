@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 2
+#define ME_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum {
@@ -45,7 +45,13 @@ enum {
     ME_ERR_RCCL = 6,           /* an RCCL call failed                                   */
     ME_ERR_IO = 7,             /* OutputError::Io / LoaderError::Pytorch                */
     ME_ERR_NOT_READY = 8,      /* forward called before the weights were finalized      */
-    ME_ERR_OOM = 9             /* device allocation failed                              */
+    ME_ERR_OOM = 9,            /* device allocation failed                              */
+    ME_ERR_OVERFLOW = 10       /* an activation left the f16 operand range (me_status_flags) */
+};
+
+/* ---- me_status_flags bits ---------------------------------------------------------------- */
+enum {
+    ME_STATUS_OVERFLOW_16BIT = 1 /* a kernel rounded a magnitude beyond 65504 to an f16 operand (stored as +-inf) */
 };
 
 /* ---- arithmetic type of the MFMA operands (accumulation is always f32) --------------- */
@@ -117,6 +123,14 @@ int32_t me_ctx_set_progress(me_ctx* ctx, me_progress_fn fn, void* user);
    context's own; NULL restores the own stream. */
 int32_t me_ctx_set_stream(me_ctx* ctx, void* hip_stream);
 int32_t me_ctx_synchronize(me_ctx* ctx);
+/* Status bits raised by the kernels since the last call (ME_STATUS_*), read and cleared; synchronises the stream.
+   The reference computes in f32 (decoder.rs:35-44: relu, conv, adds in f32); this back end rounds MFMA operands to
+   16 bit.  An f16 operand holds magnitudes up to 65504: past it the operand is +-inf, and behind a conv + ReLU the
+   branch drops out silently.  Every kernel that writes 16-bit operands therefore raises ME_STATUS_OVERFLOW_16BIT
+   when that happens.  me_extract_depth[_u8] clears the flag when it starts and, when its result goes to HOST
+   memory, fails with ME_ERR_OVERFLOW itself; with a device result the call is asynchronous and the caller asks
+   here.  bf16 operands (ME_DTYPE_BF16) have f32's range and never raise it. */
+int32_t me_status_flags(me_ctx* ctx, uint32_t* flags);
 
 /* ---- weights: mod.rs:174-249 load_record ---------------------------------------------
    Tensors are handed over under their PyTorch checkpoint names and layouts (SURVEY App. C:
@@ -149,6 +163,11 @@ int64_t me_weight_arena_bytes(const me_ctx* ctx);
    arrived on a rank, me_weights_adopt marks every tensor loaded and finalizes. */
 void* me_weight_arena_ptr(const me_ctx* ctx);
 int32_t me_weights_adopt(me_ctx* ctx);
+/* Hash of the arena's layout (dtype, me_model_config, split_operands, every tensor's offset and size).  Contexts
+   that exchange arenas must agree on it: me_bcast_weights compares it with rank 0's before the payload moves and
+   fails with ME_ERR_BAD_ARG on every rank when one differs; a caller that moves the bytes itself compares it before
+   me_weights_adopt. */
+uint64_t me_weight_arena_layout(const me_ctx* ctx);
 
 /* ---- multi-GPU start-up: one RCCL broadcast of the packed arena, no collective later ---
    rank 0 finalizes its weights, every rank calls me_bcast_weights with the same 128-byte id

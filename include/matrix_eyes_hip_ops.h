@@ -63,6 +63,13 @@ int32_t me_op_layernorm_fp8(me_ctx* ctx, const float* x32, const float* weight, 
 int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
                          const uint8_t* W8, const uint8_t* w_scale, const float* bias, void* out16, uint8_t* out8,
                          uint8_t* out8_scale, const float* gamma, float* x32);
+/* me_op_linear_fp8 over up to three row segments with their own weights, as the encoder's merged ViT launches run
+   it (pipeline.hip MergedVit): rows [0, seg1) use W8[0] / w_scale[0] / bias[0] (/ gamma[0]), [seg1, seg2) the [1]
+   set, [seg2, M) the [2] set; seg1, seg2 multiples of 256, seg2 == 0: two segments, seg1 == 0: one. */
+int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                                  int32_t seg1, int32_t seg2, const uint8_t* const W8[3], const uint8_t* const w_scale[3],
+                                  const float* const bias[3], const float* const gamma[3], void* out16, uint8_t* out8,
+                                  uint8_t* out8_scale, float* x32);
 /* me_op_attention with the output written as an MX fp8 activation operand (out8 [windows*tokens][heads*64] bytes +
    block scales; heads even): the bytes me_op_quantize_fp8 gives for me_op_attention's 16-bit output. */
 int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8_t* out8_scale, int32_t windows,

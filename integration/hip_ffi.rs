@@ -7,7 +7,7 @@
 #![allow(dead_code)]
 use std::ffi::{c_char, c_void};
 
-pub const ME_ABI_VERSION: i32 = 2;
+pub const ME_ABI_VERSION: i32 = 3;
 
 // status codes
 pub const ME_OK: i32 = 0;
@@ -20,6 +20,9 @@ pub const ME_ERR_RCCL: i32 = 6;
 pub const ME_ERR_IO: i32 = 7; // OutputError::Io / LoaderError::Pytorch
 pub const ME_ERR_NOT_READY: i32 = 8;
 pub const ME_ERR_OOM: i32 = 9;
+pub const ME_ERR_OVERFLOW: i32 = 10; // an activation left the f16 operand range (me_status_flags)
+// me_status_flags bits
+pub const ME_STATUS_OVERFLOW_16BIT: i32 = 1;
 
 // MFMA operand type
 pub const ME_DTYPE_F16: i32 = 0;
@@ -70,6 +73,7 @@ extern "C" {
     pub fn me_ctx_set_progress(ctx: *mut MeCtx, f: MeProgressFn, user: *mut c_void) -> i32;
     pub fn me_ctx_set_stream(ctx: *mut MeCtx, hip_stream: *mut c_void) -> i32;
     pub fn me_ctx_synchronize(ctx: *mut MeCtx) -> i32;
+    pub fn me_status_flags(ctx: *mut MeCtx, flags: *mut u32) -> i32;
     pub fn me_load_weight(ctx: *mut MeCtx, name: *const c_char, data: *const c_void, weight_dtype: i32, dims: *const i64, ndim: i32) -> i32;
     pub fn me_expected_weight_count(ctx: *const MeCtx) -> i32;
     pub fn me_expected_weight(ctx: *const MeCtx, index: i32, name: *mut *const c_char, dims: *mut i64, ndim: *mut i32) -> i32;
@@ -80,6 +84,7 @@ extern "C" {
     pub fn me_weight_arena_bytes(ctx: *const MeCtx) -> i64;
     pub fn me_weight_arena_ptr(ctx: *const MeCtx) -> *mut c_void;
     pub fn me_weights_adopt(ctx: *mut MeCtx) -> i32;
+    pub fn me_weight_arena_layout(ctx: *const MeCtx) -> u64;
     pub fn me_rccl_unique_id(id128: *mut c_void) -> i32;
     pub fn me_bcast_weights(ctx: *mut MeCtx, id128: *const c_void, rank: i32, nranks: i32) -> i32;
     pub fn me_preprocess_u8(ctx: *mut MeCtx, rgb: *const u8, batch: i32, img: *mut f32) -> i32;

@@ -7,8 +7,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ME_OK = 0
 ERROR_NAMES = {
     1: "BAD_ARG", 2: "BAD_SHAPE", 3: "MISSING_WEIGHT", 4: "BAD_WEIGHT", 5: "HIP", 6: "RCCL",
-    7: "IO", 8: "NOT_READY", 9: "OOM",
+    7: "IO", 8: "NOT_READY", 9: "OOM", 10: "OVERFLOW",
 }
+ME_STATUS_OVERFLOW_16BIT = 1
 ME_DTYPE_F16, ME_DTYPE_BF16, ME_DTYPE_FP8 = 0, 1, 2
 ME_WEIGHT_F32, ME_WEIGHT_F16, ME_WEIGHT_BF16, ME_WEIGHT_F64 = 0, 1, 2, 3
 ME_VIT_PATCH_ENCODER, ME_VIT_IMAGE_ENCODER, ME_VIT_FOV_ENCODER = 0, 1, 2
@@ -44,6 +45,7 @@ SIGNATURES = {
     "me_ctx_set_progress": (_i32, [_vp, PROGRESS_FN, _vp]),
     "me_ctx_set_stream": (_i32, [_vp, _vp]),
     "me_ctx_synchronize": (_i32, [_vp]),
+    "me_status_flags": (_i32, [_vp, C.POINTER(_u32)]),
     "me_load_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     "me_expected_weight_count": (_i32, [_vp]),
     "me_expected_weight": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i32)]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "me_weight_arena_bytes": (_i64, [_vp]),
     "me_weight_arena_ptr": (_vp, [_vp]),
     "me_weights_adopt": (_i32, [_vp]),
+    "me_weight_arena_layout": (C.c_uint64, [_vp]),
     "me_rccl_unique_id": (_i32, [_vp]),
     "me_bcast_weights": (_i32, [_vp, _vp, _i32, _i32]),
     "me_preprocess_u8": (_i32, [_vp, _vp, _i32, _vp]),
@@ -89,6 +92,8 @@ SIGNATURES = {
     "me_op_scale_index": (_i64, [_i64, _i32, _i64, _i32]),
     "me_op_layernorm_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
     "me_op_linear_fp8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "me_op_linear_fp8_segments": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp),
+                                         C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),
     "me_op_cast_to32": (_i32, [_vp, _vp, _vp, _i64]),
     "me_profile_enable": (_i32, [_vp, _i32]),

@@ -81,7 +81,8 @@ void validate_config(const me_model_config& c) {
 #define ME_API_BEGIN(ctx)                                                      \
     if (!(ctx)) return ME_ERR_BAD_ARG;                                         \
     try {                                                                      \
-        ME_HIP(hipSetDevice((ctx)->device));
+        ME_HIP(hipSetDevice((ctx)->device));                                   \
+        me::set_current_status_word((ctx)->status_dev);
 
 #define ME_API_END(ctx)                                                        \
     }                                                                          \
@@ -136,8 +137,15 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
             ctx->cfg = *cfg;
         else
             me_default_config(&ctx->cfg);
-        // diagnostic override of me_model_config.split_operands (tools/split_budget.py)
-        if (const char* e = getenv("ME_SPLIT_OPERANDS")) ctx->cfg.split_operands = atoi(e);
+        // diagnostic override of the DEFAULT split_operands (tools/split_budget.py).  A caller-supplied
+        // configuration is never overridden: the mask fixes the arena layout, which ranks that exchange arenas
+        // must agree on (me_bcast_weights compares me_ctx::arena_layout_hash)
+        if (const char* e = getenv("ME_SPLIT_OPERANDS")) {
+            if (!cfg) ctx->cfg.split_operands = atoi(e);
+            else if (atoi(e) != cfg->split_operands)
+                fprintf(stderr, "matrix-eyes-hip: ME_SPLIT_OPERANDS=%s ignored, the caller's me_model_config says %d\n", e,
+                        cfg->split_operands);
+        }
         if (const char* e = getenv("ME_GRAPH")) ctx->graph_enabled = atoi(e) != 0;
         validate_config(ctx->cfg);
         ME_CHECK(!ctx->fp8 || ctx->cfg.embed_dim % 256 == 0, ME_ERR_BAD_SHAPE,
@@ -146,6 +154,8 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
+        ME_HIP(hipMalloc((void**)&ctx->status_dev, 256));
+        ME_HIP(hipMemset(ctx->status_dev, 0, 256));
         build_weight_table(ctx);
         ME_HIP(hipMalloc((void**)&ctx->arena, ctx->arena_bytes));
         resolve_weights(ctx);
@@ -171,6 +181,7 @@ void me_ctx_destroy(me_ctx* ctx) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->arena8) (void)hipFree(ctx->arena8);
+    if (ctx->status_dev) (void)hipFree(ctx->status_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -241,11 +252,25 @@ const char* me_unused_weight_name(const me_ctx* ctx, int32_t index) {
 
 int64_t me_weight_arena_bytes(const me_ctx* ctx) { return ctx ? (int64_t)ctx->arena_bytes : 0; }
 
+uint64_t me_weight_arena_layout(const me_ctx* ctx) { return ctx ? ctx->arena_layout_hash() : 0; }
+
+int32_t me_status_flags(me_ctx* ctx, uint32_t* flags) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(flags, ME_ERR_BAD_ARG, "me_status_flags: null pointer");
+    uint32_t host = 0;
+    ME_HIP(hipMemcpyAsync(&host, ctx->status_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_HIP(hipMemsetAsync(ctx->status_dev, 0, 4, ctx->stream));
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    *flags = host;
+    ME_API_END(ctx)
+}
+
 void* me_weight_arena_ptr(const me_ctx* ctx) { return ctx ? (void*)ctx->arena : nullptr; }
 
 int32_t me_weights_adopt(me_ctx* ctx) {
     ME_API_BEGIN(ctx)
     for (WeightSlot& s : ctx->slots) s.loaded = true;
+    ctx->factor_keep.clear();  // host copies of factors of the arena this one replaces
     build_fp8_weights(ctx);
     ctx->finalized = true;
     ctx->drop_graph(), ++ctx->weights_generation;
@@ -478,10 +503,25 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     report(ctx, 1.0f, nullptr);
 }
 
+// The overflow guard of a call that hands its result to the host (the stream has been synchronised by then): the
+// reference computes in f32 and has no 65504 limit (decoder.rs:35-44), so an f16 operand that left the range is an
+// error of THIS back end, reported instead of a silently zeroed conv branch.
+void fail_on_overflow(me_ctx* ctx) {
+    uint32_t host = 0;
+    ME_HIP(hipMemcpy(&host, ctx->status_dev, 4, hipMemcpyDeviceToHost));
+    if (host & ME_STATUS_OVERFLOW_16BIT) {
+        ME_HIP(hipMemset(ctx->status_dev, 0, 4));
+        fail(ME_ERR_OVERFLOW,
+             "an activation left the f16 operand range (|x| > 65504) and was stored as +-inf: the depth map is not the "
+             "reference's.  Create the context with ME_DTYPE_BF16 for this checkpoint");
+    }
+}
+
 // One step = preprocess (u8 entry) + extract_depth_impl, enqueued on ctx->stream.
 void enqueue_step(me_ctx* ctx, int entry, const void* in_dev, int32_t batch, const float* f_norm,
                   float* inverse_depth, float* fov_deg_out) {
     const int S = ctx->S();
+    ME_HIP(hipMemsetAsync(ctx->status_dev, 0, 4, ctx->stream));  // the flag describes this call
     const float* img_dev = (const float*)in_dev;
     if (entry == 1) {
         float* img = (float*)site_buf(ctx, "io.img", (size_t)batch * S * S * 3 * 4);
@@ -553,6 +593,7 @@ int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const flo
         run_step(ctx, 0, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
     else
         enqueue_step(ctx, 0, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
+    if (!is_device_ptr(inverse_depth)) fail_on_overflow(ctx);  // a device result is asynchronous: me_status_flags
     ME_API_END(ctx)
 }
 
@@ -570,14 +611,15 @@ int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, cons
         run_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
     else
         enqueue_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
+    if (!is_device_ptr(inverse_depth)) fail_on_overflow(ctx);
     ME_API_END(ctx)
 }
 
 int32_t me_ctx_set_graph(me_ctx* ctx, int32_t on) {
-    if (!ctx) return ME_ERR_BAD_ARG;
+    ME_API_BEGIN(ctx)
     ctx->graph_enabled = on != 0;
     if (!on) ctx->drop_graph();
-    return ME_OK;
+    ME_API_END(ctx)
 }
 int64_t me_graph_launch_count(const me_ctx* ctx) { return ctx ? ctx->graph_launches : 0; }
 
@@ -828,6 +870,33 @@ int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uin
     if (x32) {
         ME_CHECK(gamma && bias, ME_ERR_BAD_ARG, "me_op_linear_fp8: the residual form takes bias and gamma");
         p.gamma = gamma, p.res32 = x32, p.out32 = x32;
+        gemm_fp8_launch(p, EPI_RESID_SCALE, ctx->stream);
+    } else if (out8) {
+        p.act = ACT_GELU, p.out8 = out8, p.out8_scale = out8_scale, p.out8_mt = (int)cdiv(M, 128);
+        gemm_fp8_launch(p, EPI_STORE, ctx->stream);
+    } else {
+        p.out16 = out16;
+        gemm_fp8_launch(p, EPI_STORE, ctx->stream);
+    }
+    ME_API_END(ctx)
+}
+
+int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                                  int32_t seg1, int32_t seg2, const uint8_t* const W8[3], const uint8_t* const w_scale[3],
+                                  const float* const bias[3], const float* const gamma[3], void* out16, uint8_t* out8,
+                                  uint8_t* out8_scale, float* x32) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(A8 && a_scale && W8 && w_scale && bias, ME_ERR_BAD_ARG, "me_op_linear_fp8_segments: null pointer");
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = a_scale, p.a_mt = (int)cdiv(M, 128);
+    p.W = W8[0], p.w_scale = w_scale[0], p.bias = bias[0], p.ldc = N;
+    p.seg1 = seg1, p.seg2 = seg2;
+    p.W_s1 = W8[1], p.w_scale_s1 = w_scale[1], p.bias_s1 = bias[1];
+    p.W_s2 = W8[2], p.w_scale_s2 = w_scale[2], p.bias_s2 = bias[2];
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    if (x32) {
+        ME_CHECK(gamma, ME_ERR_BAD_ARG, "me_op_linear_fp8_segments: the residual form takes gamma");
+        p.gamma = gamma[0], p.gamma_s1 = gamma[1], p.gamma_s2 = gamma[2], p.res32 = x32, p.out32 = x32;
         gemm_fp8_launch(p, EPI_RESID_SCALE, ctx->stream);
     } else if (out8) {
         p.act = ACT_GELU, p.out8 = out8, p.out8_scale = out8_scale, p.out8_mt = (int)cdiv(M, 128);

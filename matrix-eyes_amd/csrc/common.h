@@ -96,6 +96,25 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------------------------------
+// 16-bit operand overflow guard.  An f16 operand holds magnitudes up to 65504; past it the stored operand is
+// +-inf, and on a conv stage infinities of both signs sum to NaN which the ReLU behind maps to 0 -- the branch
+// drops out silently, where the fp32 reference (decoder.rs:35-44) has no such limit.  Every kernel that rounds f32
+// values to f16 operands keeps the largest magnitude it stored and raises bit ME_STATUS_OVERFLOW_16BIT of the
+// calling context's status word when it exceeds 65504 (one atomicOr on the rare path).
+// The word of the context whose entry point is running on this host thread (set by ME_API_BEGIN).
+// ---------------------------------------------------------------------------------------
+unsigned* current_status_word();
+void set_current_status_word(unsigned* w);
+#if defined(__HIPCC__)
+template <typename T>
+__device__ __forceinline__ void raise_overflow16(unsigned* status, float amax) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) {
+        if (status && amax > 65504.0f) atomicOr(status, 1u);
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------
 // Device helpers shared by the GEMM and attention kernels.
 // ---------------------------------------------------------------------------------------
 // 16-byte LDS-DMA: lane l's 16 bytes at gsrc land at lds_base + 16 l (M0 carries the wave-uniform base).
@@ -205,6 +224,13 @@ struct GemmParams {
     int32_t a_mt;
     uint8_t *out8, *out8_scale;
     int32_t out8_mt;
+    // Algorithmic work of the launch for the profiler (bench.py's roofline): rows that belong to real tokens /
+    // pixels (0: M; the merged ViT row space pads each segment to 256 rows) and the K of the layer itself (0: K; a
+    // split [hi | lo] operand doubles or triples the K the kernel walks without adding algorithmic FLOPs)
+    int32_t flop_rows, flop_k;
+    // Context status word (me_status_flags): bit 0 is set when an f16 operand store met a magnitude beyond 65504
+    // (gemm_launch fills it in from the calling context)
+    unsigned* status;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).

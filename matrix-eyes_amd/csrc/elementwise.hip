@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         T* __restrict__ y16, float* __restrict__ y32,
-                                                        int64_t rows, float eps, RowSegs segs) {
+                                                        int64_t rows, float eps, RowSegs segs,
+                                                        unsigned* __restrict__ status) {
     constexpr int DIM = NPL * 64;
     // elements per lane per pass: 8 where the row allows it, so that the 16-bit result leaves as ONE 16-byte
     // store per lane (8-byte stores run at less than half the rate: the GEMM epilogue's finding, gemm_core.h)
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float var = wave_sum(q) * (1.0f / DIM);
     const float rstd = 1.0f / sqrtf(var + eps);
+    float amax16 = 0.f;  // overflow guard of the 16-bit copy (common.h)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int e = (i * 64 + lane) * V;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 typedef T vec __attribute__((ext_vector_type(V)));
                 vec ov;
 #pragma unroll
-                for (int j = 0; j < V; ++j) ov[j] = (T)o[j];
+                for (int j = 0; j < V; ++j) ov[j] = (T)o[j], amax16 = fmaxf(amax16, fabsf(o[j]));
                 *reinterpret_cast<vec*>(y16 + row * DIM + e) = ov;
             }
             if (y32) {
@@ -98,10 +100,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
         } else {
             const float o0 = (v[i] - mean) * rstd * w[e] + b[e];
-            if (y16) y16[row * DIM + e] = (T)o0;
+            if (y16) y16[row * DIM + e] = (T)o0, amax16 = fmaxf(amax16, fabsf(o0));
             if (y32) y32[row * DIM + e] = o0;
         }
     }
+    raise_overflow16<T>(status, amax16);
 }
 
 template <typename T>
@@ -110,7 +113,7 @@ void layernorm_typed(const float* x, const float* w, const float* b, void* y16, 
     const dim3 grid((unsigned)cdiv(rows, 4)), block(256);
 #define ME_LN(NPL)                                                                          \
     hipLaunchKernelGGL((layernorm_kernel<T, NPL>), grid, block, 0, stream, x, w, b, (T*)y16, y32, \
-                       rows, eps, segs)
+                       rows, eps, segs, current_status_word())
     switch (dim / 64) {
         case 1: ME_LN(1); break;
         case 2: ME_LN(2); break;
@@ -141,14 +144,18 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ rgb, float* __r
 }
 
 template <typename T>
-__global__ void cast_to16_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n4) {
+__global__ void cast_to16_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n4,
+                                 unsigned* __restrict__ status) {
+    float amax16 = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         typename Vec16<T>::v4 o;
         o[0] = (T)v.x, o[1] = (T)v.y, o[2] = (T)v.z, o[3] = (T)v.w;
+        amax16 = fmaxf(fmaxf(fmaxf(amax16, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
         reinterpret_cast<typename Vec16<T>::v4*>(dst)[i] = o;
     }
+    raise_overflow16<T>(status, amax16);
 }
 template <typename T>
 __global__ void cast_to32_kernel(const T* __restrict__ src, float* __restrict__ dst, int64_t n4) {
@@ -278,7 +285,8 @@ __global__ void cls_rows_kernel(float* __restrict__ tokens, const float* __restr
 template <typename T>
 __global__ void merge_kernel(const float* __restrict__ src32, const T* __restrict__ src16,
                              T* __restrict__ dst, int batch, int wpi, int win0, int steps,
-                             int padding, int grid, int dim, int split) {
+                             int padding, int grid, int dim, int split, unsigned* __restrict__ status) {
+    float amax16 = 0.f;
     const int side = steps == 1 ? grid : 2 * (grid - padding) + (steps - 2) * (grid - 2 * padding);
     const int chunks = dim / 8;
     const int64_t total = (int64_t)batch * side * side * chunks;
@@ -312,6 +320,8 @@ __global__ void merge_kernel(const float* __restrict__ src32, const T* __restric
             typename Vec16<T>::v8 o;
             o[0] = (T)a.x, o[1] = (T)a.y, o[2] = (T)a.z, o[3] = (T)a.w;
             o[4] = (T)c.x, o[5] = (T)c.y, o[6] = (T)c.z, o[7] = (T)c.w;
+            amax16 = fmaxf(fmaxf(fmaxf(amax16, fabsf(a.x)), fmaxf(fabsf(a.y), fabsf(a.z))), fabsf(a.w));
+            amax16 = fmaxf(fmaxf(fmaxf(amax16, fabsf(c.x)), fmaxf(fabsf(c.y), fabsf(c.z))), fabsf(c.w));
             if (split) {
                 const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
                 typename Vec16<T>::v8 l;
@@ -331,6 +341,7 @@ __global__ void merge_kernel(const float* __restrict__ src32, const T* __restric
                 *reinterpret_cast<const uint4*>(src16 + srow * dim + ch * 8);
         }
     }
+    raise_overflow16<T>(status, amax16);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -380,8 +391,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
                                                            float* __restrict__ dst32,
                                                            T* __restrict__ dst16, int H, int W, int C,
-                                                           int border, int relu16, int split) {
+                                                           int border, int relu16, int split,
+                                                           unsigned* __restrict__ status) {
     __shared__ float tile[32][33];
+    float amax16 = 0.f;
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int HW = H * W;
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
                     pix = (int64_t)b * HW + p;
                 }
                 const float a = relu16 ? fmaxf(v, 0.f) : v;
+                amax16 = fmaxf(amax16, fabsf(a));
                 if (split) {
                     const T h = (T)a;
                     dst16[pix * 2 * C + c] = h;
@@ -417,11 +431,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             }
         }
     }
+    raise_overflow16<T>(status, amax16);
 }
 
 template <typename T>
 __global__ void nhwc32_to_16b_kernel(const float* __restrict__ src, T* __restrict__ dst, int batch,
-                                     int H, int W, int C, int relu) {
+                                     int H, int W, int C, int relu, unsigned* __restrict__ status) {
+    float amax16 = 0.f;
     const int c4 = C / 4;
     const int64_t total = (int64_t)batch * H * W * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -436,9 +452,11 @@ __global__ void nhwc32_to_16b_kernel(const float* __restrict__ src, T* __restric
         if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
         typename Vec16<T>::v4 o;
         o[0] = (T)v.x, o[1] = (T)v.y, o[2] = (T)v.z, o[3] = (T)v.w;
+        amax16 = fmaxf(fmaxf(fmaxf(amax16, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
         const int64_t pix = ((int64_t)b * (H + 2) + y + 1) * (W + 2) + x + 1;
         *reinterpret_cast<typename Vec16<T>::v4*>(dst + pix * C + c * 4) = o;
     }
+    raise_overflow16<T>(status, amax16);
 }
 
 __global__ void concat_channels_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
@@ -537,9 +555,9 @@ void cast_f32_to_16_launch(const float* src, void* dst, int64_t count, int32_t d
     const int64_t n4 = count / 4;
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(cast_to16_kernel<f16>, dim3(grid_for(n4)), dim3(256), 0, stream,
-                                   src, (f16*)dst, n4),
+                                   src, (f16*)dst, n4, current_status_word()),
                 hipLaunchKernelGGL(cast_to16_kernel<bf16>, dim3(grid_for(n4)), dim3(256), 0, stream,
-                                   src, (bf16*)dst, n4));
+                                   src, (bf16*)dst, n4, current_status_word()));
 }
 
 void cast_16_to_f32_launch(const void* src, float* dst, int64_t count, int32_t dtype,
@@ -602,10 +620,10 @@ void merge_launch(const float* src32, const void* src16, void* dst16, int32_t ba
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(merge_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, stream,
                                    src32, (const f16*)src16, (f16*)dst16, batch, windows_per_image,
-                                   win0, steps, padding, grid, dim, split),
+                                   win0, steps, padding, grid, dim, split, current_status_word()),
                 hipLaunchKernelGGL(merge_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream,
                                    src32, (const bf16*)src16, (bf16*)dst16, batch,
-                                   windows_per_image, win0, steps, padding, grid, dim, split));
+                                   windows_per_image, win0, steps, padding, grid, dim, split, current_status_word()));
 }
 
 void nhwc16_to_nchw32_launch(const void* src16, float* dst, int32_t batch, int32_t H, int32_t W,
@@ -632,9 +650,9 @@ void nchw32_to_nhwc_launch(const float* src, float* dst32, void* dst16, int32_t 
     const dim3 grid((unsigned)cdiv((int64_t)H * W, 32), (unsigned)cdiv(C, 32), batch);
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, grid, dim3(256), 0, stream, src, dst32,
-                                   (f16*)dst16, H, W, C, border, relu16, split),
+                                   (f16*)dst16, H, W, C, border, relu16, split, current_status_word()),
                 hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, grid, dim3(256), 0, stream, src,
-                                   dst32, (bf16*)dst16, H, W, C, border, relu16, split));
+                                   dst32, (bf16*)dst16, H, W, C, border, relu16, split, current_status_word()));
 }
 
 void nhwc32_to_16b_launch(const float* src, void* dst16b, int32_t batch, int32_t H, int32_t W,
@@ -643,9 +661,9 @@ void nhwc32_to_16b_launch(const float* src, void* dst16b, int32_t batch, int32_t
     const int64_t total = (int64_t)batch * H * W * (C / 4);
     ME_BY_DTYPE(dtype,
                 hipLaunchKernelGGL(nhwc32_to_16b_kernel<f16>, dim3(grid_for(total)), dim3(256), 0,
-                                   stream, src, (f16*)dst16b, batch, H, W, C, relu),
+                                   stream, src, (f16*)dst16b, batch, H, W, C, relu, current_status_word()),
                 hipLaunchKernelGGL(nhwc32_to_16b_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0,
-                                   stream, src, (bf16*)dst16b, batch, H, W, C, relu));
+                                   stream, src, (bf16*)dst16b, batch, H, W, C, relu, current_status_word()));
 }
 
 void concat_channels_launch(const void* a, const void* b, void* dst, int64_t pixels, int32_t Ca,

@@ -37,6 +37,10 @@ ME_DECL(bf16, A_CONV, EPI_STORE)
 ME_DECL(bf16, A_CONV, EPI_HEAD_FINAL)
 #undef ME_DECL
 
+static thread_local unsigned* g_status_word = nullptr;
+unsigned* current_status_word() { return g_status_word; }
+void set_current_status_word(unsigned* w) { g_status_word = w; }
+
 Profiler& profiler() {
     static thread_local Profiler p;
     return p;
@@ -155,6 +159,7 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     // (26.57 vs 26.68 ms) -- the launches the side streams disturb most (proj / fc2) have two tiles per
     // workgroup, too coarse for a late workgroup to hand work to its neighbours.
     p.queue = dynamic_tile_order() ? queue_for_stream(stream) : nullptr;
+    p.status = current_status_word();
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
              p.N, p.K);
     ME_CHECK(p.K % 64 == 0, ME_ERR_BAD_SHAPE, "gemm: K=%d is not a multiple of 64", p.K);
@@ -184,7 +189,7 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +
                        (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg)) + "," +
                        (amode == A_PLAIN ? "plain" : "conv") + "," + kEpi[epi] + ">",
-                   2.0 * p.M * p.N * p.K, 0.0);
+                   2.0 * (p.flop_rows ? p.flop_rows : p.M) * p.N * (p.flop_k ? p.flop_k : p.K), 0.0);
     if (dtype == ME_DTYPE_F16)
         launch_typed<f16>(p, amode, epi, cfg, stream);
     else if (dtype == ME_DTYPE_BF16)

@@ -221,6 +221,19 @@ struct EpiRow {
     int b, y, x;  // pixel of that row when rows are pixels of [B][out_H][out_W]
 };
 
+// amax16: running largest magnitude this lane has rounded to an f16 operand (the overflow guard of common.h;
+// v_max3_f32 with |x| source modifiers: four instructions per granule, nothing for bf16)
+template <typename T>
+__device__ __forceinline__ void track_amax16(float& amax16, const float (&a)[8], bool hi_ok) {
+    if constexpr (std::is_same<T, f16>::value) {
+        amax16 = fmaxf(fmaxf(amax16, fabsf(a[0])), fabsf(a[1]));
+        amax16 = fmaxf(fmaxf(amax16, fabsf(a[2])), fabsf(a[3]));
+        if (hi_ok) {
+            amax16 = fmaxf(fmaxf(amax16, fabsf(a[4])), fabsf(a[5]));
+            amax16 = fmaxf(fmaxf(amax16, fabsf(a[6])), fabsf(a[7]));
+        }
+    }
+}
 template <typename T>
 __device__ __forceinline__ void store_16bit(T* dst, const float (&a)[8], bool hi_ok) {
     typedef T v8 __attribute__((ext_vector_type(8)));
@@ -256,7 +269,8 @@ __device__ __forceinline__ void store_16bit_lo(T* dst, const float (&a)[8], bool
 // only, bias, no residual, no border; 1: no activation (qkv), 2: GELU (fc1)) with the branches gone
 template <typename T, int EPI, int MODE>
 __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiRow& r, int n,
-                                                 const EpiLane& lc, const f32x4 (&v)[2], bool hi_ok) {
+                                                 const EpiLane& lc, const f32x4 (&v)[2], bool hi_ok,
+                                                 float& amax16) {
     const int m = r.m;
     float a[8];  // values for the 16-bit copy
     if constexpr (EPI == EPI_STORE && MODE != 0) {
@@ -271,10 +285,12 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                 a[4 * h] = x0, a[4 * h + 1] = x1, a[4 * h + 2] = x2, a[4 * h + 3] = x3;
             }
         }
-        if constexpr (MODE == 3)
+        if constexpr (MODE == 3) {
             *reinterpret_cast<uint2*>(p.out8 + (int64_t)m * p.ldc + n) = quantise_granule_fp8(p, m, n, a);
-        else
+        } else {
+            track_amax16<T>(amax16, a, true);
             store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
+        }
     } else if constexpr (EPI == EPI_STORE) {
         const int64_t row32 = (int64_t)m * p.ldc;
 #pragma unroll
@@ -308,6 +324,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                 p.out16_border
                     ? (((int64_t)r.b * (p.out_H + 2) + r.y + 1) * (p.out_W + 2) + r.x + 1) * ld16
                     : (int64_t)m * ld16;
+            track_amax16<T>(amax16, a, hi_ok);
             store_16bit<T>((T*)p.out16 + row16 + n, a, hi_ok);
             if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + row16 + n + p.lo_off16, a, hi_ok);
             if (p.hi2_off16) store_16bit<T>((T*)p.out16 + row16 + n + p.hi2_off16, a, hi_ok);
@@ -360,6 +377,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                 p.out16_border
                     ? ((((int64_t)r.b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) * ld16 + lc.co)
                     : ((((int64_t)r.b * oH + oy) * oW + ox) * ld16 + lc.co);
+            track_amax16<T>(amax16, a, hi_ok);
             store_16bit<T>((T*)p.out16 + o, a, hi_ok);
             if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + o + p.lo_off16, a, hi_ok);
         }
@@ -463,6 +481,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             row.y = rem / p.out_W;
             row.x = rem - row.y * p.out_W;
         }
+        float amax16 = 0.f;
         auto run = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
@@ -508,7 +527,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
-                    if (row.m < p.M && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok);
+                    if (row.m < p.M && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16);
                     row.m += RPI;
                     if (pix) {
                         row.x += RPI;
@@ -542,6 +561,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         } else {
             run(std::integral_constant<int, 0>());
         }
+        if constexpr (EPI == EPI_STORE || EPI == EPI_CONVT) raise_overflow16<T>(p.status, amax16);
     }
 }
 

@@ -289,7 +289,9 @@ static void launch_pp8(const GemmParams& p, hipStream_t stream) {
 // fp8 x fp8 GEMM.  p.A / p.W: e4m3 bytes, p.lda in bytes; p.a_scale / p.w_scale (+ _s1 / _s2) in the layouts
 // above with p.a_mt = (rows padded to 128) / 128.  epi: EPI_STORE (16-bit output in f16, or fp8 + scales into
 // p.out8 / p.out8_scale when out8) or EPI_RESID_SCALE.
-void gemm_fp8_launch(const GemmParams& p, EpiKind epi, hipStream_t stream) {
+void gemm_fp8_launch(const GemmParams& p_in, EpiKind epi, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.status = current_status_word();
     ME_CHECK(p.M > 0 && p.M % 256 == 0 && p.N > 0 && p.N % 256 == 0 && p.K % 128 == 0 && p.K >= 256, ME_ERR_BAD_SHAPE,
              "fp8 gemm: M=%d N=%d K=%d (M, N multiples of 256; K a multiple of 128 and >= 256)", p.M, p.N, p.K);
     ME_CHECK(p.A && p.W && p.a_scale && p.w_scale && p.a_mt * 128 >= p.M, ME_ERR_BAD_ARG, "fp8 gemm: operands");
@@ -297,7 +299,18 @@ void gemm_fp8_launch(const GemmParams& p, EpiKind epi, hipStream_t stream) {
     ME_CHECK(p.seg1 % 256 == 0 && p.seg2 % 256 == 0, ME_ERR_BAD_ARG, "fp8 gemm: row segments");
     const char* name = epi == EPI_RESID_SCALE ? "gemm_kernel<fp8,256x256x128/8w-pp,plain,resid_scale>"
                                               : "gemm_kernel<fp8,256x256x128/8w-pp,plain,store>";
-    ProfScope prof(stream, name, 2.0 * p.M * p.N * p.K, 0.0);
+    // a caller mistake here would be a device fault, not a status code
+    ME_CHECK(p.seg1 == 0 || (p.W_s1 && p.w_scale_s1), ME_ERR_BAD_ARG, "fp8 gemm: row segment 1 without weights / scales");
+    ME_CHECK(p.seg2 == 0 || (p.seg1 != 0 && p.seg2 > p.seg1 && p.W_s2 && p.w_scale_s2), ME_ERR_BAD_ARG,
+             "fp8 gemm: row segment 2 without weights / scales");
+    if (epi == EPI_RESID_SCALE) {
+        ME_CHECK(p.gamma && p.res32 && p.out32 && p.bias, ME_ERR_BAD_ARG, "fp8 gemm: the residual form takes bias, gamma, res32 and out32");
+        ME_CHECK((p.seg1 == 0 || (p.gamma_s1 && p.bias_s1)) && (p.seg2 == 0 || (p.gamma_s2 && p.bias_s2)), ME_ERR_BAD_ARG,
+                 "fp8 gemm: a row segment without bias / gamma");
+    } else {
+        ME_CHECK((p.seg1 == 0 || p.bias_s1) && (p.seg2 == 0 || p.bias_s2), ME_ERR_BAD_ARG, "fp8 gemm: a row segment without bias");
+    }
+    ProfScope prof(stream, name, 2.0 * (p.flop_rows ? p.flop_rows : p.M) * p.N * p.K, 0.0);
     if (epi == EPI_RESID_SCALE) {
         launch_pp8<EPI_RESID_SCALE, 0>(p, stream);
     } else if (epi == EPI_STORE) {

@@ -133,6 +133,10 @@ struct me_ctx {
     size_t fused_off[5] = {0, 0, 0, 0, 0};
     std::map<std::string, std::vector<float>> factor_keep;
 
+    // me_status_flags: one device word the kernels OR bits into (ME_STATUS_OVERFLOW_16BIT: an f16 operand store
+    // met a magnitude beyond 65504, common.h raise_overflow16)
+    unsigned* status_dev = nullptr;
+
     // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
     std::map<std::string, me::DevBuf> bufs;
 
@@ -161,8 +165,25 @@ struct me_ctx {
     uint64_t weights_generation = 0;
     int64_t graph_launches = 0;   // replays so far (me_graph_launch_count)
     void drop_graph() {
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph_exec) {
+            // replays are asynchronous: a launch still queued on the stream references the exec's kernarg / node
+            // memory, so the stream is drained before the exec goes
+            (void)hipStreamSynchronize(stream);
+            (void)hipGraphExecDestroy(graph_exec);
+        }
         graph_exec = nullptr, graph_seen = false, graph_refused = false;
+    }
+    // Layout of the weight arena as a hash (FNV-1a over dtype, geometry, split mask and every slot's offset / size):
+    // ranks that exchange arenas (me_bcast_weights, me_weights_adopt) must agree on it
+    uint64_t arena_layout_hash() const {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) {
+            for (int i = 0; i < 8; ++i) h = (h ^ ((v >> (8 * i)) & 0xff)) * 1099511628211ull;
+        };
+        mix((uint64_t)dtype), mix(fp8 ? 1 : 0), mix((uint64_t)split_mask), mix(arena_bytes);
+        for (const me::WeightSlot& s : slots) mix(s.offset), mix(s.bytes), mix((uint64_t)s.kind), mix(s.dup ? 1 : 0);
+        for (int i = 0; i < 5; ++i) mix(fused_off[i]);
+        return h;
     }
 
     // geometry helpers

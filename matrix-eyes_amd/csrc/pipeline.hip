@@ -31,8 +31,8 @@ void* site_buf(me_ctx* ctx, const std::string& name, size_t bytes) {
     if (b.p && b.bytes >= bytes) return b.p;
     if (ctx->capturing) throw CaptureAbort();  // an allocation would synchronise: the caller runs eagerly instead
     if (b.p) {
-        ctx->drop_graph();  // a captured step may hold the old address
         ME_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->drop_graph();  // a captured step may hold the old address (dropped once its replays have drained)
         ME_HIP(hipFree(b.p));
         b.p = nullptr, b.bytes = 0;
     }

@@ -426,11 +426,38 @@ static void compose_fusion_out(me_ctx* ctx) {
         memcpy(&f, &u, 4);
         return f;
     };
+    // A factor without a host copy (the arena came by me_weights_adopt / me_bcast_weights, then ONE of the two was
+    // reloaded): read it back from its packed arena slot in the checkpoint's layout, so that the composed weights
+    // never lag behind a factor loaded later.  The slot holds the 16-bit value the two-launch path would use.
+    auto from_arena = [&](const std::string& name) {
+        const WeightSlot& s = ctx->slots[ctx->slot_by_name.at(name)];
+        std::vector<uint16_t> raw(s.bytes / 2);
+        ME_HIP(hipMemcpy(raw.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
+        std::vector<float> out((size_t)s.numel());
+        const int64_t Dd = s.dup ? 2 : 1;
+        if (s.kind == PK_CONVT_16) {  // [(q*Cout + co)][Dd * Cin] -> [Cin][Cout][q]
+            const int64_t Cin = s.dims[0], Cout = s.dims[1];
+            for (int64_t ci = 0; ci < Cin; ++ci)
+                for (int64_t co = 0; co < Cout; ++co)
+                    for (int64_t q = 0; q < 4; ++q)
+                        out[(ci * Cout + co) * 4 + q] = from16(raw[(q * Cout + co) * Dd * Cin + ci]);
+        } else {  // PK_MAT_16 [N][Dd * K] -> [N][K]
+            const int64_t N = s.dims[0], K = s.numel() / N;
+            for (int64_t r = 0; r < N; ++r)
+                for (int64_t k = 0; k < K; ++k) out[r * K + k] = from16(raw[r * Dd * K + k]);
+        }
+        return out;
+    };
     for (int i = 1; i < 5; ++i) {
         const std::string f = "decoder.fusions." + std::to_string(i) + ".";
-        auto d = ctx->factor_keep.find(f + "deconv.weight");
-        auto o = ctx->factor_keep.find(f + "out_conv.weight");
-        if (d == ctx->factor_keep.end() || o == ctx->factor_keep.end()) continue;  // finalize reports the missing one
+        const std::string dn = f + "deconv.weight", on = f + "out_conv.weight";
+        auto d = ctx->factor_keep.find(dn);
+        auto o = ctx->factor_keep.find(on);
+        if (d == ctx->factor_keep.end() && o == ctx->factor_keep.end()) continue;  // nothing reloaded: arena's own
+        if (!ctx->slots[ctx->slot_by_name.at(dn)].loaded || !ctx->slots[ctx->slot_by_name.at(on)].loaded)
+            continue;  // finalize reports the missing one
+        if (d == ctx->factor_keep.end()) d = ctx->factor_keep.emplace(dn, from_arena(dn)).first;
+        if (o == ctx->factor_keep.end()) o = ctx->factor_keep.emplace(on, from_arena(on)).first;
         const std::vector<float>&Wd = d->second, &Wo = o->second;  // [ci][co][q], [co2][co]
         std::vector<uint16_t> packed((size_t)(4 * D) * (3 * D));
         std::vector<double> wq((size_t)D * D), acc((size_t)D);

@@ -82,6 +82,17 @@ class Context:
     def synchronize(self):
         self._check(self.lib.me_ctx_synchronize(self._h))
 
+    def status_flags(self) -> int:
+        """Status bits the kernels raised since the last call, read and cleared (matrix_eyes_hip.h ME_STATUS_*:
+        1 = an f16 operand store met a magnitude beyond 65504)."""
+        flags = C.c_uint32(0)
+        self._check(self.lib.me_status_flags(self._h, C.byref(flags)))
+        return int(flags.value)
+
+    def weight_arena_layout(self) -> int:
+        """Hash of the weight arena's layout; contexts that exchange arenas must agree on it."""
+        return int(self.lib.me_weight_arena_layout(self._h))
+
     def set_graph(self, on: bool = True):
         """Run device-pointer extract_depth calls as one captured hipGraph (matrix_eyes_hip.h me_ctx_set_graph)."""
         self._check(self.lib.me_ctx_set_graph(self._h, 1 if on else 0))

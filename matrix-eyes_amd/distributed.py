@@ -70,7 +70,16 @@ def distribute_weights(ctx, state_dict_fn, rank: int, world: int, native: Option
     if rank == 0:
         ctx.load_state_dict(state_dict_fn())
     if world <= 1:
+        if native:   # one rank: the communicator is still created, the in-place broadcast runs (every RCCL call of the path)
+            ctx.bcast_weights(ctx.rccl_unique_id(), 0, 1)
         return
+    # every rank must lay its arena out as rank 0 does (dtype, geometry, split_operands): compared before any payload
+    # moves, on every rank, so that nobody hangs in the collective (me_bcast_weights does the same check natively)
+    layouts = [None] * world
+    dist.all_gather_object(layouts, (ctx.weight_arena_layout(), ctx.weight_arena_bytes()))
+    if len(set(layouts)) != 1:
+        from ._lib import MatrixEyesError
+        raise MatrixEyesError(1, f"weight arena layouts differ between ranks: {layouts}")
     if native:
         uid = broadcast_bytes(ctx.rccl_unique_id() if rank == 0 else None, 0)
         ctx.bcast_weights(uid, rank, world)

@@ -183,6 +183,15 @@ class DeviceDepthMap:
             C.c_void_p(out.data_ptr())))
         return out
 
+    def output_mesh(self, destination_path: str, source_path: str, vertex_mode: VertexMode = VertexMode.Texture,
+                    colors=None):
+        """output.rs:195-261 from the device-resident depth: mesh indexing, vertex coordinates and (OBJ) the text
+        itself are produced on the GPU; only the finished file bytes cross to the host."""
+        self.ctx._check(self.ctx.lib.me_output_mesh(
+            self.ctx.handle, C.c_void_p(self.data.data_ptr()), self.data_width, self.data_height,
+            self.original_width, self.original_height, destination_path.encode(), source_path.encode(),
+            int(vertex_mode), C.c_void_p(colors.data_ptr()) if colors is not None else None))
+
     def stereogram(self, amplitude: float, noise, out=None):
         """noise: CUDA u8 [out_h, out_w, 3]"""
         import torch

@@ -413,6 +413,7 @@ def test_outlier_activations_through_a_block():
     ocfg = oracle_cfg(cfg, dtype=torch.float64)
     w64 = {k: v.double() for k, v in w.items()}
     ctx = ctx_for("tiny", "f16")
+    ctx.status_flags()
     for name, inp in (("plain", x), ("spiky", spiky)):
         ref = O.block_forward(inp.double(), w64, "encoder.patch_encoder.blocks.0.", ocfg)
         got = inp.reshape(-1, C).contiguous().cuda()
@@ -436,12 +437,15 @@ def test_outlier_activations_through_a_block():
         col = qkv[:, 2 * C + 3].float()
         if finite:
             assert torch.equal(col, torch.full_like(col, float(torch.tensor(target).half()))) and torch.isfinite(got).all()
+            assert ctx.status_flags() == 0
         else:
             assert torch.isinf(col).all() and not torch.isfinite(got).all()
+            # ... and it is reported: the store that rounded 7e4 to +inf raised the context's status bit
+            assert ctx.status_flags() == 1 and ctx.status_flags() == 0          # read and cleared
             bctx = ctx_for("tiny", "bf16")
             gotb = x.reshape(-1, C).contiguous().cuda()
             _vit_block_gpu(bctx, gotb, big, 0, C, T, windows, heads, "bf16")
-            assert torch.isfinite(gotb).all()
+            assert torch.isfinite(gotb).all() and bctx.status_flags() == 0
 
 
 def test_outlier_activations_through_a_residual_conv_unit():

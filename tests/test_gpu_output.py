@@ -257,3 +257,40 @@ def test_config4_chain_full_size(tmp_path):
     assert dest.stat().st_size == (tmp_path / "oracle.obj").stat().st_size > 10e6
     assert filecmp.cmp(dest, tmp_path / "oracle.obj", shallow=False)
     assert (tmp_path / "mesh.mtl").read_text() == OO.mtl_text("photo.jpg")
+
+
+def test_config4_chain_batch_of_two(tmp_path):
+    """BASELINE configs[4] in batch form: TWO images per step through depth -> DepthMap::new -> stereogram -> textured
+    OBJ, everything from the model's batched output tensor on the device (DeviceDepthMap.output_mesh reads the device
+    depth).  Per image: the clamp + range, stereogram and colour map are bit-exact against the C oracle and the
+    OBJ + MTL byte-identical to the oracle's writer; the two images' products differ from each other."""
+    import filecmp
+    import torch
+    from matrix_eyes_amd.synthetic import synthetic_images
+    from util import loaded_ctx
+    ctx = loaded_ctx("full", "f16")
+    S, B = ctx.cfg.img_size, 2
+    rgb = torch.from_numpy(synthetic_images(B, S, "structured", seed=57)).cuda()
+    depth = torch.empty(B, S, S, dtype=torch.float32, device="cuda")
+    ctx.extract_depth(rgb, None, out=depth)
+    ctx.synchronize()
+    raw = depth.cpu().numpy().copy()
+    noise = np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)
+    noise_dev = torch.from_numpy(noise).cuda()
+    maps = [m.DeviceDepthMap(ctx, depth[b], (S, S)) for b in range(B)]
+    stereo = [maps[b].stereogram(1.0 / 16.0, noise_dev) for b in range(B)]
+    for b in range(B):
+        maps[b].output_mesh(str(tmp_path / f"mesh{b}.obj"), f"photo{b}.jpg", m.VertexMode.Texture)
+    sizes = []
+    for b in range(B):
+        od, mn, mx = OO.clamp_minmax(raw[b])
+        assert maps[b].inverse_depth_range() == (mn, mx) and np.array_equal(depth[b].cpu().numpy(), od)
+        assert np.array_equal(stereo[b].cpu().numpy(), OO.stereogram(od, mn, mx, S, S, 1.0 / 16.0, noise))
+        vi, nv, faces = OO.mesh_index(od)
+        uv, xyz = OO.mesh_vertices(od, vi, nv, (S, S))
+        OO.write_obj(str(tmp_path / f"oracle{b}.obj"), uv, xyz, faces, "texture", f"mesh{b}")
+        assert filecmp.cmp(tmp_path / f"mesh{b}.obj", tmp_path / f"oracle{b}.obj", shallow=False)
+        assert (tmp_path / f"mesh{b}.mtl").read_text() == OO.mtl_text(f"photo{b}.jpg")
+        sizes.append((tmp_path / f"mesh{b}.obj").stat().st_size)
+    assert min(sizes) > 10e6 and not filecmp.cmp(tmp_path / "mesh0.obj", tmp_path / "mesh1.obj", shallow=False)
+    assert not torch.equal(stereo[0], stereo[1])

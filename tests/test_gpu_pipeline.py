@@ -157,6 +157,17 @@ def test_captured_graph_replays_the_eager_step(dtype):
         ctx.extract_depth(rgb, f_norm, out=other)            # another output pointer: eager again
         ctx.synchronize()
         assert ctx.graph_launch_count == n0 + 4 and torch.equal(other, out)
+        # a key change right behind a replay, nothing synchronised in between: the exec is destroyed only once
+        # its queued launch has drained (me_ctx::drop_graph), so the replay's result is intact
+        ctx.extract_depth(rgb, f_norm, out=out)
+        ctx.extract_depth(rgb, f_norm, out=out)
+        n1 = ctx.graph_launch_count
+        out.zero_()
+        ctx.extract_depth(rgb, f_norm, out=out)              # replay, in flight ...
+        third = torch.empty_like(out)
+        ctx.extract_depth(rgb, f_norm, out=third)            # ... when the new pointer drops its exec
+        ctx.synchronize()
+        assert ctx.graph_launch_count == n1 + 1 and torch.equal(out, other) and torch.equal(third, other)
         host = ctx.extract_depth(noise.cpu().numpy(), None if f_norm is None else f_norm.cpu().numpy())
         assert np.array_equal(host, out.cpu().numpy())       # host pointers: eager, same bits
     n0 = ctx.graph_launch_count
@@ -263,6 +274,37 @@ def test_missing_and_unexpected_weights():
     ctx.close()
 
 
+def test_f16_overflow_is_reported_not_swallowed():
+    """VERDICT r2 item 9.  The reference computes in f32 (decoder.rs:35-44); an f16 operand past 65504 is +-inf, and
+    behind a conv + ReLU the branch silently drops out (test_outlier_activations_through_a_residual_conv_unit).  A
+    checkpoint whose encoder projection is scaled by 3e5 drives the un-diluted conv chain past the range: the
+    call that returns to the host fails with ME_ERR_OVERFLOW, the asynchronous (device-output) call raises
+    ME_STATUS_OVERFLOW_16BIT for me_status_flags, the bf16 context computes the same model finitely with no flag,
+    and the untouched checkpoint raises nothing."""
+    cfg = m.ModelConfig.tiny()
+    w = dict(weights_for("tiny"))
+    rgb = synthetic_images(1, cfg.img_size)
+    good = loaded_ctx("tiny", "f16")
+    good.status_flags()
+    good.extract_depth(rgb, None)
+    assert good.status_flags() == 0
+    w["encoder.upsample_latent0.0.weight"] = (torch.as_tensor(w["encoder.upsample_latent0.0.weight"]).float() * 3.0e5)
+    ctx = m.Context(0, "f16", cfg)
+    ctx.load_state_dict(w)
+    with pytest.raises(m.MatrixEyesError) as e:
+        ctx.extract_depth(rgb, 1.0)
+    assert e.value.code == 10 and "65504" in e.value.message
+    out = torch.empty(1, cfg.img_size, cfg.img_size, dtype=torch.float32, device="cuda")
+    ctx.extract_depth(torch.from_numpy(rgb).cuda(), 1.0, out=out)      # asynchronous: no error here ...
+    assert ctx.status_flags() == 1 and ctx.status_flags() == 0          # ... the flag says so, once
+    ctx.close()
+    bctx = m.Context(0, "bf16", cfg)
+    bctx.load_state_dict(w)
+    d = bctx.extract_depth(rgb, 1.0)
+    assert np.isfinite(d).all() and bctx.status_flags() == 0
+    bctx.close()
+
+
 def test_weight_arena_handover():
     """The multi-GPU start-up path on one GPU: a second context receives only the packed arena bytes
     (what the broadcast delivers), adopts them and must produce bit-identical depth."""
@@ -279,6 +321,37 @@ def test_weight_arena_handover():
     d0, f0 = src.extract_depth(rgb, None, want_fov=True)
     d1, f1 = dst.extract_depth(rgb, None, want_fov=True)
     assert np.array_equal(d0, d1) and f0[0] == f1[0]
+    dst.close()
+
+
+def test_one_reloaded_fusion_factor_recomposes_the_fused_weights():
+    """a context whose arena came by me_weights_adopt holds no host copies of the deconv / out_conv
+    factors that the composed fusion weights (split_operands & 2) are built from.  Reloading ONE of them and
+    finalizing must recompose with the other factor read back from the arena -- the depth equals that of a context
+    loaded with the modified checkpoint from scratch, not the stale composition."""
+    src = loaded_ctx("tiny", "f16")
+    assert src.cfg.split_operands & 2
+    w = dict(weights_for("tiny"))
+    name = "decoder.fusions.2.out_conv.weight"
+    w[name] = (torch.as_tensor(w[name]).float() * 1.5).half()
+    rgb = synthetic_images(1, src.cfg.img_size)
+    fresh = m.Context(0, "f16", src.cfg)
+    fresh.load_state_dict(w)
+    want = fresh.extract_depth(rgb, 1.0)
+    fresh.close()
+    dst = m.Context(0, "f16", src.cfg)
+    assert dst.weight_arena_layout() == src.weight_arena_layout() != 0
+    dst.weight_arena_tensor().copy_(src.weight_arena_tensor())
+    torch.cuda.synchronize()
+    dst.adopt_weights()
+    before = dst.extract_depth(rgb, 1.0)
+    dst.load_weight(name, w[name])
+    dst._check(dst.lib.me_weights_finalize(dst.handle))
+    got = dst.extract_depth(rgb, 1.0)
+    assert not np.array_equal(before, got) and np.array_equal(got, want)
+    other = m.Context(0, "f16", m.ModelConfig(**{**src.cfg.__dict__, "split_operands": 0}))
+    assert other.weight_arena_layout() != src.weight_arena_layout()      # what me_bcast_weights compares
+    other.close()
     dst.close()
 
 
@@ -307,22 +380,76 @@ def full_oracle():
     return img, ref.numpy(), float(ref_fov[0])
 
 
-def test_extract_depth_full_size(full_oracle):
-    """BASELINE configs[1]: one 1536x1536 image through the full-size model (951.99 M synthetic parameters),
-    FOV head on, f16 operands, against the fp32 oracle.  north_star: depth within 1e-3 relative of the CPU
-    reference -- asserted as such.  Measured: relative L2 7.1e-4, median per-pixel relative error 1.4e-4 with the
-    default split-operand stages (me_model_config.split_operands = 3); 1.01e-3 / 2.0e-4 without them."""
-    ctx = loaded_ctx("full", "f16")
-    cfg = ctx.cfg
-    assert cfg.img_size == m.IMG_SIZE == 1536 and cfg.split_operands == 3
-    assert ctx.weight_arena_bytes() > 1.9e9
-    img, ref, ref_fov = full_oracle
+# (image family, image seed, checkpoint seed): SURVEY 8d names `structured` / 4321 for parity and `noise` / 1234 for
+# throughput; the third pair changes BOTH the image and the 952 M weights
+FULL_PAIRS = [("structured", 4321, 2024), ("noise", 1234, 2024), ("structured", 77, 7)]
+
+
+@pytest.mark.parametrize("family,img_seed,ckpt_seed", FULL_PAIRS)
+def test_extract_depth_full_size_pairs(family, img_seed, ckpt_seed, full_oracle):
+    """north_star: depth within 1e-3 relative of the CPU reference -- held on three (image, checkpoint) pairs, not one:
+    relative L2 < 1e-3 on each, and the per-pixel distribution bounded too (median, 99th percentile and maximum of
+    |d - ref| / max(|ref|, 0.05 median(ref)); the floor keeps the pixels that the closing ReLU zeroes -- clamped to
+    1e-4 on both sides -- from dividing by ~0).  Measured (f16, split_operands 3), round 3:
+        structured/4321, ckpt 2024: rel-L2 7.1e-4, median 1.4e-4, p99 2.3e-2
+    The per-pixel tail sits next to the ReLU's zero crossing, where a 2^-11 operand rounding decides between 0 and a
+    small positive value; it is bounded, not 1e-3."""
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint
+    cfg = m.ModelConfig()
+    if (family, img_seed, ckpt_seed) == FULL_PAIRS[0]:
+        img, ref, ref_fov = full_oracle
+        ctx, own = loaded_ctx("full", "f16"), False
+        assert cfg.img_size == m.IMG_SIZE == 1536 and ctx.cfg.split_operands == 3 and ctx.weight_arena_bytes() > 1.9e9
+    else:
+        w = weights_for("full") if ckpt_seed == 2024 else synthetic_checkpoint(cfg, seed=ckpt_seed)
+        img = O.preprocess_u8(synthetic_images(1, cfg.img_size, family, seed=img_seed))
+        r, rf = O.extract_depth(img, None, w, oracle_cfg(cfg))
+        ref, ref_fov = r.numpy(), float(rf[0])
+        if ckpt_seed == 2024:
+            ctx, own = loaded_ctx("full", "f16"), False
+        else:
+            ctx, own = m.Context(0, "f16", cfg), True
+            ctx.load_state_dict(w)
+        del w
     got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
+    if own:
+        ctx.close()
     rep = depth_error_report(got, ref)
-    print("full-size f16", rep, float(fov[0]), ref_fov)
+    print("full-size f16 pair", family, img_seed, ckpt_seed, rep, float(fov[0]), ref_fov)
     assert rep["rel_l2"] < 1.0e-3
-    assert rep["median"] < 2.0e-4
+    assert rep["median"] < 2.5e-4
+    assert rep["p99"] < 5.0e-2
+    assert rep["max"] < 2.0
     assert abs(float(fov[0]) - ref_fov) < 0.05
+
+
+# SURVEY App. D: Burn 0.21's LayerNorm eps and bilinear convention are ASSUMED (1e-5, align_corners = true); the other
+# choice of each is a parameter of both the oracle and the HIP path, and both choices are held to the oracle here
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("ln_eps", [1e-5, 1e-6])
+def test_assumed_semantics_branches_tiny(align_corners, ln_eps):
+    base = m.ModelConfig.tiny()
+    cfg = m.ModelConfig(**{**base.__dict__, "align_corners": align_corners, "ln_eps": ln_eps})
+    w = weights_for("tiny")
+    ctx = m.Context(0, "f16", cfg)
+    ctx.load_state_dict(w)
+    ocfg = oracle_cfg(cfg)
+    assert ocfg.align_corners == align_corners and ocfg.ln_eps == ln_eps
+    img = _img(cfg, family="noise")          # high-frequency content: the two bilinear conventions differ visibly on it
+    inv, fov, parts = O.extract_depth(img, None, w, ocfg, return_parts=True)
+    enc = ctx.encoder_forward_encodings(img.numpy())
+    for got, ref in zip(enc, parts["encodings"]):
+        assert rel_l2(got, ref) < 1.5 * TOL["f16"]
+    got, gfov = ctx.extract_depth(img.numpy(), None, want_fov=True)
+    rep = depth_error_report(got, inv.numpy())
+    print("branches", align_corners, ln_eps, rep)
+    assert rep["rel_l2"] < 2 * TOL["f16"] and abs(float(gfov[0]) - float(fov[0])) < 0.05
+    # the test means something only if the branch changes the answer by more than the tolerance it is held to
+    other = O.extract_depth(img, None, w, oracle_cfg(m.ModelConfig(**{**cfg.__dict__, "align_corners": not align_corners})))[0]
+    assert rel_l2(other, inv) > 10 * rep["rel_l2"]
+    other = O.extract_depth(img, None, w, oracle_cfg(m.ModelConfig(**{**cfg.__dict__, "ln_eps": 1e-6 if ln_eps == 1e-5 else 1e-5})))[0]
+    print("eps branch moves the depth by", rel_l2(other, inv))
+    ctx.close()
 
 
 def test_split_operand_stages_buy_the_margin(full_oracle):
@@ -368,8 +495,23 @@ def test_extract_depth_full_size_fp8(full_oracle):
     got, fov = ctx.extract_depth(img.numpy(), None, want_fov=True)
     rep = depth_error_report(got, ref)
     print("full-size fp8", rep, float(fov[0]), ref_fov)
-    assert np.isfinite(got).all() and rep["rel_l2"] < 1.5e-1
+    assert np.isfinite(got).all() and rep["rel_l2"] < 1.0e-1          # measured 7.8e-2: the bound is 1.3x that
     assert abs(float(fov[0]) - ref_fov) < 2.0
+
+
+def test_full_size_fp8_batch_of_eight():
+    """BASELINE configs[3] at its per-GPU batch: 8 images per step on the fp8 context.  Images 1 and 6 of the batch
+    are bit for bit what a batch of one produces (other tile rounds, 280 + 8 + 8 windows), all depths finite and inside
+    the clamp of mod.rs:362."""
+    ctx = loaded_ctx("full", "fp8")
+    rgb = synthetic_images(8, ctx.cfg.img_size, "structured", seed=123)
+    batch, fovs = ctx.extract_depth(rgb, None, want_fov=True)
+    assert batch.shape == (8, 1536, 1536) and np.isfinite(batch).all() and np.isfinite(fovs).all()
+    assert batch.min() >= 1e-4 and batch.max() <= 1e4
+    for i in (1, 6):
+        one, fov1 = ctx.extract_depth(rgb[i:i + 1], None, want_fov=True)
+        assert np.array_equal(batch[i], one[0]) and fovs[i] == fov1[0]
+    assert len({batch[i].tobytes() for i in range(8)}) == 8
 
 
 def test_full_size_batch_of_eight():
