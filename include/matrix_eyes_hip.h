@@ -288,6 +288,21 @@ int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t h
                        const char* destination_path, const char* source_path, int32_t vertex_mode,
                        const uint8_t* vertex_colors);
 
+/* The OBJ text of me_output_mesh without the file: the mesh is indexed and every "vt" / "v" / "f" line formatted on
+   the GPU (output.rs:484-630 ObjWriter; numbers as Rust's `{}` prints an f64), the lines packed in the reference's
+   order behind the "mtllib <stem>.mtl" / "usemtl Textured" header of texture mode.  *text_dev: DEVICE address of the
+   bytes, owned by the context and valid until its next mesh call; *nbytes: their count.  me_output_mesh(".obj") is
+   this text copied to the host once and written to the file. */
+int32_t me_mesh_obj_text(me_ctx* ctx, const float* depth, int32_t width, int32_t height, uint32_t original_width,
+                         uint32_t original_height, const char* stem, int32_t vertex_mode,
+                         const uint8_t* vertex_colors, const uint8_t** text_dev, int64_t* nbytes);
+
+/* Where the last me_output_mesh(".obj") call on this context spent its time, host wall clock in milliseconds:
+   ms_out[0] mesh indexing + vertex kernels (incl. their read-back of the counts), [1] the text formatting kernels,
+   [2] the D2H copy of the text into pinned memory, [3] the file write (the host kernel's page-cache copy);
+   *text_bytes (optional): the size of the file. */
+int32_t me_last_mesh_timing(const me_ctx* ctx, double ms_out[4], int64_t* text_bytes);
+
 #ifdef __cplusplus
 }
 #endif

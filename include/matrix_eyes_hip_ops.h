@@ -74,6 +74,10 @@ int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, 
    block scales; heads even): the bytes me_op_quantize_fp8 gives for me_op_attention's 16-bit output. */
 int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8_t* out8_scale, int32_t windows,
                             int32_t tokens, int32_t heads);
+/* The number formatter of the device OBJ writer (csrc/ryu_f64.h, obj_format.hip) on its own: values[i] (DEVICE f64)
+   printed as Rust's `{}` prints an f64 -- shortest round-trip digits, positional notation -- into the `stride`-byte
+   slot i of `text` (stride >= 344), its length into lengths[i]. */
+int32_t me_op_format_f64(me_ctx* ctx, const double* values, int64_t count, char* text, int32_t stride, int32_t* lengths);
 /* f32 <-> context 16-bit type */
 int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
 int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);

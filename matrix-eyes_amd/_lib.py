@@ -78,6 +78,8 @@ SIGNATURES = {
     "me_mesh_index": (_i32, [_vp, _vp, _i32, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "me_mesh_vertices": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _u32, _u32, _vp, _vp]),
     "me_output_mesh": (_i32, [_vp, _vp, _i32, _i32, _u32, _u32, C.c_char_p, C.c_char_p, _i32, _vp]),
+    "me_mesh_obj_text": (_i32, [_vp, _vp, _i32, _i32, _u32, _u32, C.c_char_p, _i32, _vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "me_last_mesh_timing": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     # matrix_eyes_hip_ops.h
     "me_op_linear": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "me_op_linear_residual": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
@@ -94,6 +96,7 @@ SIGNATURES = {
     "me_op_linear_fp8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "me_op_linear_fp8_segments": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp),
                                          C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    "me_op_format_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),
     "me_op_cast_to32": (_i32, [_vp, _vp, _vp, _i64]),
     "me_profile_enable": (_i32, [_vp, _i32]),

@@ -182,6 +182,7 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->arena8) (void)hipFree(ctx->arena8);
     if (ctx->status_dev) (void)hipFree(ctx->status_dev);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -905,6 +906,13 @@ int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, 
         p.out16 = out16;
         gemm_fp8_launch(p, EPI_STORE, ctx->stream);
     }
+    ME_API_END(ctx)
+}
+
+int32_t me_op_format_f64(me_ctx* ctx, const double* values, int64_t count, char* text, int32_t stride, int32_t* lengths) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(values && text && lengths && count >= 0, ME_ERR_BAD_ARG, "me_op_format_f64: bad argument");
+    format_f64_launch(values, count, text, stride, lengths, ctx->stream);
     ME_API_END(ctx)
 }
 

@@ -347,5 +347,15 @@ void mesh_index_run(const float* depth_dev, int32_t width, int32_t height, int32
 void mesh_vertices_launch(const float* depth, int32_t width, int32_t height,
                           const int32_t* vertex_index, float xm, float ym, float* uv, float* xyz,
                           hipStream_t stream);
+// OBJ text on the device (obj_format.hip): measure returns the exact size (header included), write fills the buffer
+size_t obj_format_workspace_bytes(int64_t nverts, int64_t nfaces);
+int64_t obj_format_measure(const float* uv, const float* xyz, const uint8_t* vertex_rgb, const int32_t* faces,
+                           int64_t nverts, int64_t nfaces, bool tex, int64_t header_bytes, void* workspace,
+                           hipStream_t stream);
+void obj_format_write(const float* uv, const float* xyz, const uint8_t* vertex_rgb, const int32_t* faces, int64_t nverts,
+                      int64_t nfaces, bool tex, char* text, void* workspace, hipStream_t stream);
+void format_f64_launch(const double* v, int64_t n, char* out, int stride, int* lens, hipStream_t stream);
+void obj_vertex_colors_launch(const int32_t* vindex, const uint8_t* pixel_rgb, int64_t npix, uint8_t* vertex_rgb,
+                              hipStream_t stream);
 
 }  // namespace me

@@ -1147,6 +1147,216 @@ void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     ME_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The guide's 256x256 "8-phase" schedule (cdna_hip_programming.md section 5, T3 + T4) as one more tile configuration,
+// built for the A/B that VERDICT r2 item 4 asks for: the same tile, operand roles, LDS image and epilogue as the
+// two-group kernel above, but a K tile consumed in FOUR phases of 16 MFMAs per wave (one 64 x 32 quadrant of the
+// wave's 128 x 64 block over the whole 64-deep slab), each phase = {fragment reads + ONE half-tile of LDS-DMA |
+// barrier | MFMAs | barrier}, the two wave groups one barrier apart so that one group's matrix section runs beside
+// the other's load section, counted vmcnt once per K tile, raw s_barrier.
+//
+// Layout.  Two 64 KiB K-tile buffers (A rows at +0, W rows at +32 KiB; the 128-byte-row image with the chunk
+// swizzle of the kernels above), 32 KiB of epilogue scratch of its own behind them: 160 KiB.  Wave (wr, wc) owns
+// rows wr*64 + [0, 64) of EACH 128-row half of the tile (so that the first two phases read only the A half 0 and
+// free it early) and columns wc*64 + [0, 64); its weight fragments are read once per K tile and kept.
+//   phase 1: reads W(n-tiles 0,1) + A half 0 (12 x ds_read_b128)   MFMAs (mh 0, nh 0)   stages W half 1 of tile k+1
+//   phase 2: reads W(n-tiles 2,3)            (4)                   MFMAs (mh 0, nh 1)   stages A half 1 of tile k+1
+//   phase 3: reads A half 1                  (8)                   MFMAs (mh 1, nh 1)   stages A half 0 of tile k+2
+//   phase 4: --                                                    MFMAs (mh 1, nh 0)   stages W half 0 of tile k+2
+// Every half is restaged two phases or more after its last read (WAR), and read one phase or more after the counted
+// wait that retires it, the wait standing in front of phase 4's FIRST barrier so that it also covers the other
+// group, which runs one barrier behind (RAW: "read a staged buffer one phase AFTER the wait that retires it").
+// The K stream runs on across tile boundaries as in the kernels above.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_8ph_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int BUF = 65536, W_OFF = 32768, SCR_OFF = 2 * BUF, SCR = 4096;
+    typedef typename MfmaOp<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;  // waves w and w + 4 share a SIMD: the two groups are wr = 0 / 1
+    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int nk = p.K / 64;
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    struct Src {
+        int m0, n0;
+        const char *a, *w;        // uniform: the tile's first activation row / weight row
+        unsigned ao[2][2], wo[2][2];  // per-lane byte offsets of this wave's two pieces of each 128-row half
+    };
+    auto setup = [&](Src& t, int vb) {
+        tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
+        t.a = (const char*)p.A + (int64_t)t.m0 * p.lda * 2;
+        t.w = segment_weights(p, t.m0) + (int64_t)t.n0 * p.K * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int row = h * 128 + (pc * 8 + wave) * 8 + srow;
+                const int chunk = sslot ^ ((row >> 1) & 7);
+                int gm = t.m0 + row, gn = t.n0 + row;
+                gm = gm < p.M ? gm : p.M - 1;
+                gn = gn < p.N ? gn : p.N - 1;
+                t.ao[h][pc] = (unsigned)((int64_t)(gm - t.m0) * p.lda * 2) + chunk * 16;
+                t.wo[h][pc] = (unsigned)((int64_t)(gn - t.n0) * p.K * 2) + chunk * 16;
+            }
+    };
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    int vb = blockIdx.x;
+    Src cur, nxt;
+    // one half-tile: this wave's two 1 KiB pieces (8 rows each) of half h of operand `op` (0 = A, 1 = W) of slab kt
+    // of the current tile or (of_next) the next one.  The two tiles' fields are chosen by value -- a pointer to one
+    // of the two structs would put both into scratch memory, and scratch loads count in vmcnt
+    auto stage = [&](bool of_next, int kt, int b, int op, int h) {
+        const char* tb = op ? (of_next ? nxt.w : cur.w) : (of_next ? nxt.a : cur.a);
+        const char* base = uniform_ptr(tb + (int64_t)kt * 128);
+        const unsigned dst = smem_base + b * BUF + (op ? W_OFF : 0) + (h * 128 + wave * 8) * 128;
+        const unsigned o0 = op ? (of_next ? nxt.wo[h][0] : cur.wo[h][0]) : (of_next ? nxt.ao[h][0] : cur.ao[h][0]);
+        const unsigned o1 = op ? (of_next ? nxt.wo[h][1] : cur.wo[h][1]) : (of_next ? nxt.ao[h][1] : cur.ao[h][1]);
+        glds16_raw(base, o0, dst);
+        glds16_raw(base, o1, dst + 64 * 128);
+    };
+
+    const int frow = lane & 15, fswz = frow >> 1;
+    const int fslot[2] = {((lane >> 4) ^ fswz) * 16, (((lane >> 4) + 4) ^ fswz) * 16};
+    const int a_rd = (wr * 64 + frow) * 128;            // + mh * 128 rows + i * 16 rows
+    const int w_rd = W_OFF + (wc * 64 + frow) * 128;    // + j * 16 rows
+
+    setup(cur, vb);
+    int next_vb = vb + (int)gridDim.x;
+    bool has_next = next_vb < ntiles;
+    nxt = cur;
+    if (has_next) setup(nxt, next_vb);
+    // stream position d K tiles ahead of (cur, kt): 0 = in the current tile, 1 = in the next one, -1 = past the end;
+    // k = its slab
+    auto ahead = [&](int kt, int d, int& k) -> int {
+        k = kt + d;
+        if (k < nk) return 0;
+        k -= nk;
+        return has_next ? 1 : -1;
+    };
+    // prologue: K tile 0 whole, then the first two halves of K tile 1 (nk >= 2)
+    stage(false, 0, 0, 0, 0), stage(false, 0, 0, 1, 0), stage(false, 0, 0, 1, 1), stage(false, 0, 0, 0, 1);
+    stage(false, 1, 1, 0, 0), stage(false, 1, 1, 1, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) {  // group 1 runs one barrier behind group 0 from here on
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    int b = 0;  // buffer of the K tile being consumed
+
+    while (true) {
+        f32x4 acc[2][4][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + b * BUF;
+            frag af[2][4], wf[2][4];
+            int k1, k2;
+            const int t1 = ahead(kt, 1, k1), t2 = ahead(kt, 2, k2);
+            auto mfma_quadrant = [&](int mh, int nh) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[mh][i][nh * 2 + j] = MfmaOp<T>::run(wf[ks][nh * 2 + j], af[ks][i], acc[mh][i][nh * 2 + j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            };
+            auto read_w = [&](int j0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = j0; j < j0 + 2; ++j)
+                        wf[ks][j] = *reinterpret_cast<const frag*>(sb + w_rd + j * 2048 + fslot[ks]);
+            };
+            auto read_a = [&](int mh) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[ks][i] = *reinterpret_cast<const frag*>(sb + a_rd + (mh * 128 + i * 16) * 128 + fslot[ks]);
+            };
+            // ---- phase 1
+            read_w(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0);
+            if (t1 >= 0) stage(t1 == 1, k1, b ^ 1, 1, 1);
+            mfma_quadrant(0, 0);
+            // ---- phase 2
+            read_w(2);
+            if (t1 >= 0) stage(t1 == 1, k1, b ^ 1, 0, 1);
+            mfma_quadrant(0, 1);
+            // ---- phase 3
+            read_a(1);
+            if (t2 >= 0) stage(t2 == 1, k2, b, 0, 0);
+            mfma_quadrant(1, 1);
+            // ---- phase 4: K tile k+1 must have landed (its last half was issued in phase 2); the two halves of
+            // tile k+2 issued since may stay in flight
+            if (t2 >= 0) {
+                stage(t2 == 1, k2, b, 1, 0);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            mfma_quadrant(1, 0);
+            b ^= 1;
+        }
+        // epilogue of this tile: the two 128-row halves, each wave's 64 x 64 block of them, through the wave's own
+        // scratch (never restaged: the stream of the next tile keeps running underneath)
+        char* scr = smem + SCR_OFF + wave * SCR;
+        gemm_epilogue<T, EPI, 4, 4, 64, 64, 1, true>(p, acc[0], cur.m0, cur.n0, wr, wc, lane, scr);
+        gemm_epilogue<T, EPI, 4, 4, 64, 64, 1, true>(p, acc[1], cur.m0 + 128, cur.n0, wr, wc, lane, scr);
+        if (!has_next) break;
+        cur = nxt;
+        vb = next_vb;
+        next_vb = vb + (int)gridDim.x;
+        has_next = next_vb < ntiles;
+        if (has_next) setup(nxt, next_vb);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // group 1's extra barrier of the prologue, matched
+}
+
+template <typename T, int EPI>
+void gemm_launch_8ph(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = 160 * 1024;
+    ME_CHECK(p.K >= 128, ME_ERR_BAD_SHAPE, "gemm: the 8-phase kernel needs K >= 128 (K = %d)", p.K);
+    auto kern = gemm_8ph_kernel<T, EPI>;
+    static PerDeviceOnce once;
+    const int resident = per_device_once(once, [&](int dev) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int per_cu = 0, cus = 0;
+        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, smem));
+        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int r = (per_cu < 1 ? 1 : per_cu) * cus;
+        r -= r % 8;
+        return r < 8 ? 8 : r;
+    });
+    const int64_t ntiles = cdiv(p.M, 256) * cdiv(p.N, 256);
+    ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range", (long long)ntiles);
+    const int64_t grid = ntiles < resident ? ntiles : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+    ME_HIP(hipGetLastError());
+}
+
 // vmcnt(rem * P) for a run-time rem in [0, R]
 template <int R, int P>
 struct WaitSlabs {
@@ -1325,6 +1535,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 3: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 4: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
             case 5: gemm_launch_pp<T, 192, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
+            case 6:                                                                       \
+                if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \
+                    gemm_launch_8ph<T, EPI>(p, stream);                                   \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the 8-phase configuration takes plain linears only"); \
+                break;                                                                    \
             default: fail(ME_ERR_BAD_ARG, "gemm: bad tile config %d", cfg);               \
         }                                                                                 \
     }

@@ -3,6 +3,7 @@
 // host-side serialisation, byte-for-byte the reference's text/binary layout.
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,25 +13,18 @@
 #include <vector>
 
 #include "model.h"
+#include "ryu_f64.h"
 
 using namespace me;
 
 namespace {
 
-// Rust `{}` for f64: shortest digits that round-trip, positional notation, "1" for 1.0,
-// "-0" for -0.0, "NaN" / "inf" / "-inf".
+// Rust `{}` for f64: shortest digits that round-trip, positional notation, "1" for 1.0, "-0" for -0.0, "NaN" / "inf" /
+// "-inf" (ryu_f64.h: the formatter the device kernels of obj_format.hip run; std::to_chars(fixed) gives the same
+// bytes below 2^53 and prints exact integer digits beyond, where Rust pads the shortest digits with zeros).
 inline void put_f64(std::string& out, double v) {
-    if (std::isnan(v)) {
-        out += "NaN";
-        return;
-    }
-    if (std::isinf(v)) {
-        out += v < 0 ? "-inf" : "inf";
-        return;
-    }
-    char buf[400];
-    const auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
-    out.append(buf, r.ptr);
+    char buf[ryu::kMaxFixedChars + 8];
+    out.append(buf, (size_t)ryu::format_fixed(v, buf));
 }
 
 inline void put_u64(std::string& out, unsigned long long v) {
@@ -165,6 +159,158 @@ void put_be32(std::string& out, uint32_t u) {
 
 }  // namespace
 
+namespace {
+
+// Everything of output.rs:195-261 that is arithmetic, on the device: IndexedMesh::new + remap_face, the vertex
+// coordinates, and (OBJ) the text itself.
+struct DeviceMesh {
+    int64_t nverts = 0, nfaces = 0;
+    int32_t* vindex = nullptr;
+    int32_t* faces = nullptr;
+    float *uv = nullptr, *xyz = nullptr;
+};
+
+DeviceMesh build_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t height, uint32_t original_width,
+                      uint32_t original_height) {
+    DeviceMesh m;
+    const size_t nv = (size_t)width * height;
+    const size_t nt = 2 * (size_t)(width - 1) * (height - 1);
+    const float* d = (const float*)to_device(ctx, depth, nv * 4, "out.depth");
+    m.vindex = (int32_t*)site_buf(ctx, "out.vindex", nv * 4);
+    m.faces = (int32_t*)site_buf(ctx, "out.faces", nt * 12);
+    mesh_index_run(d, width, height, m.vindex, m.faces, &m.nverts, &m.nfaces,
+                   site_buf(ctx, "out.mesh.ws", mesh_workspace_bytes(width, height)), ctx->stream);
+    m.uv = (float*)site_buf(ctx, "out.uv", m.nverts * 8 + 8);
+    m.xyz = (float*)site_buf(ctx, "out.xyz", m.nverts * 12 + 12);
+    const uint32_t mx = original_width > original_height ? original_width : original_height;
+    mesh_vertices_launch(d, width, height, m.vindex, (float)original_width / (float)mx,
+                         (float)original_height / (float)mx, m.uv, m.xyz, ctx->stream);
+    return m;
+}
+
+// The OBJ text in device memory (site buffer "out.objtext"): header lines + vt / v / f sections.
+struct DeviceText {
+    char* dev = nullptr;
+    int64_t bytes = 0;
+};
+DeviceText obj_text_on_device(me_ctx* ctx, const DeviceMesh& m, int32_t width, int32_t height, const std::string& stem,
+                              int32_t vertex_mode, const uint8_t* vertex_colors) {
+    const bool tex = vertex_mode == ME_VERTEX_TEXTURE;
+    const bool with_color = vertex_mode == ME_VERTEX_COLOR && vertex_colors;
+    const uint8_t* vrgb = nullptr;
+    if (with_color) {
+        const size_t nv = (size_t)width * height;
+        const uint8_t* pix = (const uint8_t*)to_device(ctx, vertex_colors, nv * 3, "out.pixel_rgb");
+        uint8_t* v = (uint8_t*)site_buf(ctx, "out.vertex_rgb", (size_t)m.nverts * 3 + 16);
+        obj_vertex_colors_launch(m.vindex, pix, (int64_t)nv, v, ctx->stream);
+        vrgb = v;
+    }
+    std::string header;
+    if (tex) header = "mtllib " + stem + ".mtl\nusemtl Textured\n";  // output.rs:556-562
+    void* ws = site_buf(ctx, "out.objfmt.ws", obj_format_workspace_bytes(m.nverts, m.nfaces));
+    DeviceText t;
+    t.bytes = obj_format_measure(m.uv, m.xyz, vrgb, m.faces, m.nverts, m.nfaces, tex, (int64_t)header.size(), ws,
+                                 ctx->stream);
+    // the size follows the kept faces of each image: grown in 64 MiB steps so that a sequence of images settles
+    const size_t step = (size_t)64 << 20;
+    t.dev = (char*)site_buf(ctx, "out.objtext", ((size_t)t.bytes + 64 + step - 1) / step * step);
+    if (!header.empty())
+        ME_HIP(hipMemcpyAsync(t.dev, header.data(), header.size(), hipMemcpyHostToDevice, ctx->stream));
+    obj_format_write(m.uv, m.xyz, vrgb, m.faces, m.nverts, m.nfaces, tex, t.dev, ws, ctx->stream);
+    return t;
+}
+
+// `bytes` from pinned host memory into a new file: chunks of 8 MiB by up to 8 threads (page-cache copies scale
+// with threads; one thread moves ~2 GB/s)
+void write_file_parallel(const std::string& path, const char* data, size_t bytes) {
+    FILE* f = fopen(path.c_str(), "wb");
+    ME_CHECK(f, ME_ERR_IO, "cannot create %s: %s", path.c_str(), strerror(errno));
+    const int fd = fileno(f);
+    constexpr size_t kChunk = 8u << 20;
+    const int64_t nchunks = (int64_t)((bytes + kChunk - 1) / kChunk);
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::min<int64_t>(nchunks, hw ? (hw > 8 ? 8 : hw) : 4);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};
+    auto put = [&]() {
+        for (int64_t c; (c = next.fetch_add(1)) < nchunks;) {
+            size_t done = (size_t)c * kChunk;
+            const size_t end = std::min(bytes, done + kChunk);
+            while (done < end) {
+                const ssize_t r = pwrite(fd, data + done, end - done, (off_t)done);
+                if (r <= 0) {
+                    failed = errno ? errno : EIO;
+                    return;
+                }
+                done += (size_t)r;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(put);
+    put();
+    for (std::thread& t : pool) t.join();
+    const int r = fclose(f);
+    ME_CHECK(failed == 0, ME_ERR_IO, "write failed: %s", strerror(failed));
+    ME_CHECK(r == 0, ME_ERR_IO, "close failed: %s", strerror(errno));
+}
+
+// pinned staging buffer of the context (the D2H copy of a few hundred MB runs at the link rate only from pinned memory)
+char* pinned_buf(me_ctx* ctx, size_t bytes) {
+    if (ctx->pinned && ctx->pinned_bytes >= bytes) return (char*)ctx->pinned;
+    if (ctx->pinned) ME_HIP(hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr, ctx->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 4;  // meshes of one image size differ by their kept faces
+    ME_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return (char*)ctx->pinned;
+}
+
+void write_mtl(const std::string& dest, const std::string& stem, const char* source_path) {  // output.rs:525-547
+    const std::string dir = parent_dir(dest);
+    FileSink m((dir.empty() ? std::string() : dir + "/") + stem + ".mtl");
+    m.buf += "newmtl Textured\nKa 0.2 0.2 0.2\nKd 0.8 0.8 0.8\nKs 1.0 1.0 1.0\nillum 2\n";
+    m.buf += "Ns 0.000500\n";
+    m.buf += std::string("map_Ka ") + source_path + "\n";
+    m.buf += std::string("map_Kd ") + source_path + "\n\n";
+    m.close();
+}
+
+}  // namespace
+
+extern "C" int32_t me_last_mesh_timing(const me_ctx* ctx, double ms_out[4], int64_t* text_bytes) {
+    if (!ctx || !ms_out) return ME_ERR_BAD_ARG;
+    for (int i = 0; i < 4; ++i) ms_out[i] = ctx->mesh_ms[i];
+    if (text_bytes) *text_bytes = ctx->mesh_bytes;
+    return ME_OK;
+}
+
+extern "C" int32_t me_mesh_obj_text(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
+                                    uint32_t original_width, uint32_t original_height, const char* stem,
+                                    int32_t vertex_mode, const uint8_t* vertex_colors, const uint8_t** text_dev,
+                                    int64_t* nbytes) {
+    if (!ctx) return ME_ERR_BAD_ARG;
+    try {
+        ME_HIP(hipSetDevice(ctx->device));
+        ME_CHECK(depth && stem && text_dev && nbytes, ME_ERR_BAD_ARG, "me_mesh_obj_text: null pointer");
+        ME_CHECK(vertex_mode >= ME_VERTEX_PLAIN && vertex_mode <= ME_VERTEX_TEXTURE, ME_ERR_BAD_ARG,
+                 "vertex mode %d", vertex_mode);
+        ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "me_mesh_obj_text: %dx%d", width, height);
+        ME_CHECK(original_width > 0 && original_height > 0, ME_ERR_BAD_ARG, "original size 0");
+        const DeviceMesh m = build_mesh(ctx, depth, width, height, original_width, original_height);
+        const DeviceText t = obj_text_on_device(ctx, m, width, height, stem, vertex_mode, vertex_colors);
+        ME_HIP(hipStreamSynchronize(ctx->stream));
+        *text_dev = (const uint8_t*)t.dev, *nbytes = t.bytes;
+    } catch (const me::Error& e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        ctx->last_error = std::string("internal: ") + e.what();
+        return ME_ERR_BAD_ARG;
+    }
+    return ME_OK;
+}
+
 extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
                                   uint32_t original_width, uint32_t original_height,
                                   const char* destination_path, const char* source_path,
@@ -183,21 +329,42 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
         ME_CHECK(ply || obj, ME_ERR_BAD_ARG, "mesh destination must end in .obj or .ply: %s",
                  destination_path);
         const bool with_color = vertex_mode == ME_VERTEX_COLOR && vertex_colors;
+        const auto t_entry = std::chrono::steady_clock::now();
 
         // ---- GPU: IndexedMesh::new + remap_face + vertex coordinates
         const size_t nv = (size_t)width * height;
-        const size_t nt = 2 * (size_t)(width - 1) * (height - 1);
-        const float* d = (const float*)to_device(ctx, depth, nv * 4, "out.depth");
-        int32_t* vindex = (int32_t*)site_buf(ctx, "out.vindex", nv * 4);
-        int32_t* faces_dev = (int32_t*)site_buf(ctx, "out.faces", nt * 12);
-        int64_t nverts = 0, nfaces = 0;
-        mesh_index_run(d, width, height, vindex, faces_dev, &nverts, &nfaces,
-                       site_buf(ctx, "out.mesh.ws", mesh_workspace_bytes(width, height)), ctx->stream);
-        float* uv_dev = (float*)site_buf(ctx, "out.uv", nverts * 8 + 8);
-        float* xyz_dev = (float*)site_buf(ctx, "out.xyz", nverts * 12 + 12);
-        const uint32_t mx = original_width > original_height ? original_width : original_height;
-        mesh_vertices_launch(d, width, height, vindex, (float)original_width / (float)mx,
-                             (float)original_height / (float)mx, uv_dev, xyz_dev, ctx->stream);
+        const DeviceMesh mesh = build_mesh(ctx, depth, width, height, original_width, original_height);
+        const int64_t nverts = mesh.nverts, nfaces = mesh.nfaces;
+        int32_t* vindex = mesh.vindex;
+        int32_t* faces_dev = mesh.faces;
+        float *uv_dev = mesh.uv, *xyz_dev = mesh.xyz;
+        // ---- OBJ: the text is formatted on the GPU too (obj_format.hip); one D2H copy into pinned memory, one file
+        // write.  ME_OBJ_HOST_FORMAT=1 keeps the host formatter below (the same Ryu digits; A/B and PLY path).
+        static const bool host_format = getenv("ME_OBJ_HOST_FORMAT") != nullptr;
+        if (obj && !host_format) {
+            static const bool timing = getenv("ME_OBJ_TIMING") != nullptr;  // diagnostic: the legs on stderr
+            const auto now = [] { return std::chrono::steady_clock::now(); };
+            const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            const auto t0 = now();
+            const std::string stem = file_stem(dest);
+            const DeviceText t = obj_text_on_device(ctx, mesh, width, height, stem, vertex_mode, vertex_colors);
+            char* host = pinned_buf(ctx, (size_t)t.bytes);
+            ME_HIP(hipStreamSynchronize(ctx->stream));  // the legs are reported separately (me_last_mesh_timing)
+            const auto t1 = now();
+            ME_HIP(hipMemcpyAsync(host, t.dev, (size_t)t.bytes, hipMemcpyDeviceToHost, ctx->stream));
+            ME_HIP(hipStreamSynchronize(ctx->stream));
+            const auto t2 = now();
+            write_file_parallel(dest, host, (size_t)t.bytes);
+            if (vertex_mode == ME_VERTEX_TEXTURE) write_mtl(dest, stem, source_path);
+            const auto t3 = now();
+            ctx->mesh_ms[0] = ms(t_entry, t0), ctx->mesh_ms[1] = ms(t0, t1), ctx->mesh_ms[2] = ms(t1, t2), ctx->mesh_ms[3] = ms(t2, t3);
+            ctx->mesh_bytes = t.bytes;
+            if (timing)
+                fprintf(stderr, "me_output_mesh: %lld vertices, %lld faces, %lld bytes: mesh %.2f ms, format %.2f ms, D2H %.2f ms, "
+                                "file %.2f ms\n", (long long)nverts, (long long)nfaces, (long long)t.bytes, ms(t_entry, t0), ms(t0, t1),
+                        ms(t1, t2), ms(t2, t3));
+            return ME_OK;
+        }
         std::vector<float> uv((size_t)nverts * 2), xyz((size_t)nverts * 3);
         std::vector<int32_t> faces((size_t)nfaces * 3), vi;
         if (nverts) {
@@ -272,15 +439,7 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                 b += '\n';
             });
             w.close();
-            if (tex) {  // output.rs:525-547 write_materials
-                const std::string dir = parent_dir(dest);
-                FileSink m((dir.empty() ? std::string() : dir + "/") + stem + ".mtl");
-                m.buf += "newmtl Textured\nKa 0.2 0.2 0.2\nKd 0.8 0.8 0.8\nKs 1.0 1.0 1.0\nillum 2\n";
-                m.buf += "Ns 0.000500\n";
-                m.buf += std::string("map_Ka ") + source_path + "\n";
-                m.buf += std::string("map_Kd ") + source_path + "\n\n";
-                m.close();
-            }
+            if (tex) write_mtl(dest, stem, source_path);
         } else {
             // output.rs:415-438
             b += "ply\nformat binary_big_endian 1.0\ncomment Matrix Eyes 3D surface\n";

@@ -137,6 +137,14 @@ struct me_ctx {
     // met a magnitude beyond 65504, common.h raise_overflow16)
     unsigned* status_dev = nullptr;
 
+    // pinned host staging buffer (the OBJ text's D2H copy, mesh_writer.hip)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // legs of the last me_output_mesh(".obj") call, host wall clock: [0] mesh indexing + vertex kernels, [1] text
+    // formatting kernels, [2] D2H copy of the text, [3] file write (me_last_mesh_timing)
+    double mesh_ms[4] = {0, 0, 0, 0};
+    int64_t mesh_bytes = 0;
+
     // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
     std::map<std::string, me::DevBuf> bufs;
 

@@ -79,7 +79,7 @@ void linear(me_ctx* ctx, const void* A, int64_t M, int K, const void* W, int N, 
             bool out_split = false) {
     GemmParams p = base_params();
     const int Kx = a_split ? 2 * K : K;
-    p.M = (int)M, p.N = N, p.K = Kx, p.A = A, p.lda = Kx, p.W = W, p.bias = bias;
+    p.M = (int)M, p.N = N, p.K = Kx, p.flop_k = K, p.A = A, p.lda = Kx, p.W = W, p.bias = bias;
     p.out16 = out16, p.out32 = out32, p.ldc = ldc, p.act = act;
     if (out_split) set_out16_split(p, N);
     gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
@@ -102,6 +102,7 @@ void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, cons
           int k, int stride, const float* bias, const ConvOut& o, hipStream_t s, bool a_split = false) {
     GemmParams p = base_params();
     const int Ho = Hin / stride, Wo = Win / stride;
+    p.flop_k = k * k * Cin;
     if (a_split) Cin *= 2;  // pixels of [hi | lo]; the packed weights repeat each tap's Cin values
     p.M = B * Ho * Wo, p.N = Cout, p.K = k * k * Cin;
     p.A = in16b, p.in_Hp = Hin + 2, p.in_Wp = Win + 2, p.Cin = Cin;
@@ -124,6 +125,9 @@ void convt(me_ctx* ctx, const void* in16, int B, int H, int W_, int Cin, const v
     GemmParams p = base_params();
     const int Kx = k_copies > 0 ? k_copies * Cin : (a_split ? 2 * Cin : Cin);
     p.M = B * H * W_, p.N = 4 * Cout, p.K = Kx, p.A = in16, p.lda = Kx, p.W = W, p.bias = bias;
+    // the composed deconv o out_conv (k_copies == 3) stands for two layers of SURVEY App. B: ConvT (Cin x 4 Cout per
+    // input pixel) and the 1x1 conv at 4x the pixels (Cout x Cout each) -- twice the ConvT's FLOPs when Cin == Cout
+    p.flop_k = k_copies == 3 ? 2 * Cin : Cin;
     p.out_H = H, p.out_W = W_, p.Cout = Cout, p.out32 = out32, p.out16 = out16;
     p.out16_border = border16 ? 1 : 0, p.ldc = Cout, p.act = act16;
     if (out_split) {
@@ -282,6 +286,8 @@ struct MergedVit {
     RowSegs segs;
 
     static int64_t pad256(int64_t r) { return (r + 255) / 256 * 256; }
+    // rows that hold tokens (the profiler's algorithmic FLOPs; the padding rows of each segment are not work)
+    int64_t real_rows() const { return (int64_t)(W0 + W1 * (fov ? 2 : 1)) * ctx->T(); }
 
     MergedVit(me_ctx* ctx_, int B, bool fov_, const void* patches_main, const void* patches_img,
               const void* patches_fov, const VitTaps& taps_, hipStream_t s_)
@@ -344,6 +350,7 @@ struct MergedVit {
                   const float* b1, const float* b2, int N, void* out16, int act) {
         GemmParams p = base_params();
         p.M = (int)Rtot, p.N = N, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = b0;
+        p.flop_rows = (int)real_rows();
         p.out16 = out16, p.ldc = N, p.act = act;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = b1, p.W_s2 = w2, p.bias_s2 = b2;
         gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
@@ -356,6 +363,7 @@ struct MergedVit {
         const int C = ctx->C();
         GemmParams p = base_params();
         p.M = (int)Rtot, p.N = C, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = bb0, p.gamma = g0;
+        p.flop_rows = (int)real_rows();
         p.res32 = tok, p.out32 = tok, p.ldc = C;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = bb1, p.gamma_s1 = g1;
         p.W_s2 = w2, p.bias_s2 = bb2, p.gamma_s2 = g2;
@@ -378,6 +386,7 @@ struct MergedVit {
         auto bias = [&](const VitBlockW& b) { return which == 0 ? b.qkv_b : (which == 1 ? b.fc1_b : (which == 2 ? b.fc2_b : b.proj_b)); };
         auto gamma = [&](const VitBlockW& b) { return which == 3 ? b.ls1 : b.ls2; };
         p.M = (int)Rtot, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = As, p.a_mt = (int)(Rtot / 128);
+        p.flop_rows = (int)real_rows();
         p.W = w8(b0), p.w_scale = ws(b0), p.bias = bias(b0), p.ldc = N;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2;
         p.W_s1 = w8(b1), p.w_scale_s1 = ws(b1), p.bias_s1 = bias(b1);
@@ -542,7 +551,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async /* = w
     {
         GemmParams p = base_params();
         const int K = 2 * e3 * (int)wide;
-        p.M = B * H4 * H4, p.N = e3, p.K = K, p.A = cat, p.lda = K, p.W = ctx->w.fuse_w;
+        p.M = B * H4 * H4, p.N = e3, p.K = K, p.flop_k = 2 * e3, p.A = cat, p.lda = K, p.W = ctx->w.fuse_w;
         p.bias = ctx->w.fuse_b, p.out16 = enc4, p.out16_border = 1, p.ldc = e3;
         p.out_H = H4, p.out_W = H4;
         if (sp_dec) set_out16_split(p, e3);
@@ -644,7 +653,7 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
             void* f16b = site_buf(ctx, "features.16b", bordered_bytes(B, ho, ho, dec) * (sp_head ? 2 : 1));
             GemmParams p = base_params();
             const int K = dec * (int)wf;
-            p.M = (int)Mo, p.N = dec, p.K = K, p.A = pre, p.lda = K, p.W = fw.out_w;
+            p.M = (int)Mo, p.N = dec, p.K = K, p.flop_k = dec, p.A = pre, p.lda = K, p.W = fw.out_w;
             p.bias = fw.out_b, p.out16 = f16b, p.out16_border = 1, p.out32 = f32, p.ldc = dec;
             p.out_H = ho, p.out_W = ho;
             if (sp_head) set_out16_split(p, dec);
@@ -672,7 +681,7 @@ void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* 
           ACT_NONE, s, sp, sp);
     GemmParams p = base_params();
     const int hc = (dec / 2) * (int)wide;
-    p.M = B * S * S, p.N = c.head_dims[0], p.K = 9 * hc;
+    p.M = B * S * S, p.N = c.head_dims[0], p.K = 9 * hc, p.flop_k = 9 * (dec / 2);
     p.A = h1, p.in_Hp = S + 2, p.in_Wp = S + 2, p.Cin = hc, p.out_H = S, p.out_W = S;
     p.KH = 3, p.KW = 3, p.stride = 1, p.W = ctx->w.head2_w, p.bias = ctx->w.head2_b;
     p.w2 = ctx->w.head4_w, p.b2 = ctx->w.head4_b, p.f_norm = f_norm_dev;

@@ -89,6 +89,13 @@ class Context:
         self._check(self.lib.me_status_flags(self._h, C.byref(flags)))
         return int(flags.value)
 
+    def last_mesh_timing(self):
+        """legs of the last output_mesh(".obj") call in ms: {mesh, format, d2h, file} and the text size"""
+        ms = (C.c_double * 4)()
+        n = C.c_int64()
+        self._check(self.lib.me_last_mesh_timing(self._h, ms, C.byref(n)))
+        return {"mesh_ms": ms[0], "format_ms": ms[1], "d2h_ms": ms[2], "file_ms": ms[3], "bytes": int(n.value)}
+
     def weight_arena_layout(self) -> int:
         """Hash of the weight arena's layout; contexts that exchange arenas must agree on it."""
         return int(self.lib.me_weight_arena_layout(self._h))

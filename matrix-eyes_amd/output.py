@@ -192,6 +192,21 @@ class DeviceDepthMap:
             self.original_width, self.original_height, destination_path.encode(), source_path.encode(),
             int(vertex_mode), C.c_void_p(colors.data_ptr()) if colors is not None else None))
 
+    def obj_text(self, stem: str = "mesh", vertex_mode: VertexMode = VertexMode.Texture, colors=None):
+        """The OBJ file's bytes as a CUDA uint8 tensor (me_mesh_obj_text: the text formatted on the GPU; a copy of the
+        context-owned buffer)."""
+        import torch
+
+        class _DevMem:
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        ptr, n = C.c_void_p(), C.c_int64()
+        self.ctx._check(self.ctx.lib.me_mesh_obj_text(
+            self.ctx.handle, C.c_void_p(self.data.data_ptr()), self.data_width, self.data_height, self.original_width,
+            self.original_height, stem.encode(), int(vertex_mode),
+            C.c_void_p(colors.data_ptr()) if colors is not None else None, C.byref(ptr), C.byref(n)))
+        return torch.as_tensor(_DevMem(int(ptr.value), int(n.value)), device=self.data.device).clone()
+
     def stereogram(self, amplitude: float, noise, out=None):
         """noise: CUDA u8 [out_h, out_w, 3]"""
         import torch

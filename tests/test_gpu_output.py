@@ -294,3 +294,65 @@ def test_config4_chain_batch_of_two(tmp_path):
         sizes.append((tmp_path / f"mesh{b}.obj").stat().st_size)
     assert min(sizes) > 10e6 and not filecmp.cmp(tmp_path / "mesh0.obj", tmp_path / "mesh1.obj", shallow=False)
     assert not torch.equal(stereo[0], stereo[1])
+
+
+def test_device_number_formatter_prints_like_rust():
+    """obj_format.hip's digit generator on the GPU (64 x 128-bit multiplications by __umul64hi, tables in device
+    memory) against the oracle's rust_display_f64 (the shortest round-trip digits of CPython's repr laid out positionally): random
+    bit patterns over the whole f64 range, widened f32 values, 1 - v, c / 255 and the edge cases."""
+    import torch
+    ctx = _ctx()
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 2 ** 64, size=200000, dtype=np.uint64)
+    any_f64 = bits.view(np.float64)
+    f32 = rng.integers(0, 2 ** 32, size=200000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    f32 = f32[np.isfinite(f32)]
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1e21, 1e22, 1e23, 1e-7, 5e-324, 2.2250738585072014e-308,
+                        1.7976931348623157e308, 9007199254740993.0, 0.3, 1e15, 1e16, 1e17, np.inf, -np.inf, np.nan,
+                        0.10000000149011612, 1 / 3, 2 / 3, 8.5e-323])
+    vals = np.concatenate([special, any_f64[~np.isnan(any_f64)], f32.astype(np.float64), 1.0 - np.abs(f32[:50000]).astype(np.float64),
+                           np.arange(256) / 255.0, rng.uniform(-250, 250, 100000).astype(np.float32).astype(np.float64)])
+    stride = 352
+    v = torch.from_numpy(vals).cuda()
+    text = torch.zeros(len(vals) * stride, dtype=torch.uint8, device="cuda")
+    lens = torch.zeros(len(vals), dtype=torch.int32, device="cuda")
+    ctx._check(ctx.lib.me_op_format_f64(ctx.handle, v.data_ptr(), len(vals), text.data_ptr(), stride, lens.data_ptr()))
+    ctx.synchronize()
+    text, lens = text.cpu().numpy().reshape(len(vals), stride), lens.cpu().numpy()
+    step = max(1, len(vals) // 60000)           # every value's length, a dense sample's characters
+    for i in list(range(0, len(special))) + list(range(len(special), len(vals), step)):
+        want = OO.rust_display_f64(float(vals[i]))
+        got = text[i, :lens[i]].tobytes().decode()
+        assert got == want, (i, repr(float(vals[i])), got, want)
+    assert lens.min() >= 1 and lens.max() <= 344
+
+
+@pytest.mark.parametrize("mode", ["plain", "color", "texture"])
+def test_obj_text_on_device_equals_the_file_and_the_oracle(tmp_path, mode):
+    """me_mesh_obj_text: the device buffer holds exactly the bytes me_output_mesh writes, and those are the oracle
+    writer's -- on a non-square original size (xm != ym) and a depth map that spans the whole clamp range, so that
+    coordinates of every magnitude from 1e-3 to 250 (and exact zeros on the optical axis) are printed."""
+    import torch
+    ctx = _ctx()
+    n = 200
+    rng = np.random.default_rng(3)
+    d = np.exp(rng.uniform(np.log(0.004), np.log(10.0), size=(n, n))).astype(np.float32)
+    d[40:120, 30:170] = 0.25                      # a flat patch: many kept faces
+    d[:, 100] = d[:, 99]
+    dm = m.DepthMap(ctx, d, (3000, 2000))
+    vm = {"plain": m.VertexMode.Plain, "color": m.VertexMode.Color, "texture": m.VertexMode.Texture}[mode]
+    colors = rng.integers(0, 256, size=(n, n, 3), dtype=np.uint8) if mode == "color" else None
+    ddm = m.DeviceDepthMap(ctx, torch.from_numpy(dm.data).cuda(), (3000, 2000))
+    cdev = torch.from_numpy(colors).cuda() if colors is not None else None
+    text = ddm.obj_text("scene", vm, cdev).cpu().numpy().tobytes()
+    ddm.output_mesh(str(tmp_path / "scene.obj"), "photo.jpg", vm, cdev)
+    assert (tmp_path / "scene.obj").read_bytes() == text
+    vi, nv, faces = OO.mesh_index(dm.data)
+    uv, xyz = OO.mesh_vertices(dm.data, vi, nv, (3000, 2000))
+    vcol = None
+    if colors is not None:
+        vcol = np.zeros((nv, 3), np.uint8)
+        flat = colors.reshape(-1, 3)
+        vcol[vi[vi >= 0]] = flat[vi >= 0]
+    assert nv > 1000 and len(faces) > 1000
+    assert text.decode() == OO.obj_text(uv, xyz, faces, mode, "scene", vcol)

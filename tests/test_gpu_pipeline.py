@@ -391,7 +391,9 @@ def test_extract_depth_full_size_pairs(family, img_seed, ckpt_seed, full_oracle)
     relative L2 < 1e-3 on each, and the per-pixel distribution bounded too (median, 99th percentile and maximum of
     |d - ref| / max(|ref|, 0.05 median(ref)); the floor keeps the pixels that the closing ReLU zeroes -- clamped to
     1e-4 on both sides -- from dividing by ~0).  Measured (f16, split_operands 3), round 3:
-        structured/4321, ckpt 2024: rel-L2 7.1e-4, median 1.4e-4, p99 2.3e-2
+        structured/4321, ckpt 2024: rel-L2 7.11e-4, median 1.40e-4, p99 2.29e-2, max 0.45, FOV 54.90174 vs 54.90181
+        noise/1234,      ckpt 2024: rel-L2 6.86e-4, median 0.94e-4, p99 2.21e-2, max 0.51, FOV 54.75515 vs 54.75537
+        structured/77,   ckpt 7:    rel-L2 5.15e-4, median 3.31e-4, p99 1.19e-2, max 0.074, FOV 54.86040 vs 54.86039
     The per-pixel tail sits next to the ReLU's zero crossing, where a 2^-11 operand rounding decides between 0 and a
     small positive value; it is bounded, not 1e-3."""
     from matrix_eyes_amd.synthetic import synthetic_checkpoint
@@ -417,10 +419,10 @@ def test_extract_depth_full_size_pairs(family, img_seed, ckpt_seed, full_oracle)
     rep = depth_error_report(got, ref)
     print("full-size f16 pair", family, img_seed, ckpt_seed, rep, float(fov[0]), ref_fov)
     assert rep["rel_l2"] < 1.0e-3
-    assert rep["median"] < 2.5e-4
-    assert rep["p99"] < 5.0e-2
-    assert rep["max"] < 2.0
-    assert abs(float(fov[0]) - ref_fov) < 0.05
+    assert rep["median"] < 5.0e-4
+    assert rep["p99"] < 4.0e-2
+    assert rep["max"] < 1.0
+    assert abs(float(fov[0]) - ref_fov) < 0.01
 
 
 # Burn 0.21's LayerNorm eps and bilinear convention are ASSUMED (1e-5, align_corners = true); the other

@@ -69,3 +69,18 @@ def test_image_output_format_defaults():
     assert f.kind == "stereogram" and f.resize_scale is None and f.amplitude == 0.0625
     assert m.ImageOutputFormat.DepthMap().kind == "depthmap"
     assert [int(v) for v in m.VertexMode] == [0, 1, 2]
+
+
+def test_number_formatter_prints_like_rust(tmp_path):
+    """csrc/ryu_f64.h -- the shortest round-trip f64 formatter that both the host writer and the device kernels of the
+    OBJ writer run (output.rs:566-602 prints coordinates with Rust's `{}`) -- against std::to_chars(fixed) on 3.3 M
+    doubles: random bit patterns, widened f32 values and 1 - v as the writer produces them, c / 255, powers of ten and
+    two and their neighbours (tests/ryu_check.cpp states what is compared where)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ryu_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "matrix-eyes_amd", "csrc"),
+                    os.path.join(root, "tests", "ryu_check.cpp"), "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe, "500000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
