@@ -61,8 +61,10 @@ ProfScope::~ProfScope() {
 
 // Tile configurations (the ids are what me_op_* take as tile_cfg)
 static const char* kCfgNames[] = {"256x256x64/8w-pp", "128x128x64/4w", "64x64x64/4w", "160x128x64/4w",
-                                  "64x64x64/4w-ring6", "192x256x64/8w-pp", "256x256x64/8w-8ph"};
-enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_PP192 = 5, CFG_8PH = 6, CFG_COUNT = 7 };
+                                  "64x64x64/4w-ring6", "192x256x64/8w-pp", "256x256x64/8w-8ph", "96x256x64/8w-pp",
+                                  "128x256x64/8w-ring3"};
+enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_PP192 = 5, CFG_8PH = 6, CFG_PP96 = 7,
+       CFG_RING128 = 8, CFG_COUNT = 9 };
 int gemm_num_configs() { return CFG_COUNT; }
 const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < CFG_COUNT ? kCfgNames[cfg] : "?"; }
 
@@ -177,9 +179,9 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
     int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K, p.seg1, p.seg2, amode == A_PLAIN && epi == EPI_RESID_SCALE);
-    if ((cfg == CFG_PP256 || cfg == CFG_PP192 || cfg == CFG_8PH) && p.K < 128) cfg = CFG_128;  // they prefetch two slabs ahead
+    if ((cfg == CFG_PP256 || cfg == CFG_PP192 || cfg == CFG_8PH || cfg == CFG_PP96) && p.K < 128) cfg = CFG_128;  // they prefetch two slabs ahead
     {
-        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64, 192, 256};
+        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64, 192, 256, 96, 128};
         const int bm = epi == EPI_HEAD_FINAL ? 256 : kTileRows[cfg];
         ME_CHECK(p.seg1 % bm == 0 && p.seg2 % bm == 0 && (p.seg2 == 0 || p.seg2 > p.seg1), ME_ERR_BAD_ARG,
                  "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);

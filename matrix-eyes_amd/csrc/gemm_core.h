@@ -1535,6 +1535,18 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 3: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 4: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \
             case 5: gemm_launch_pp<T, 192, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
+            case 7: /* short tail tile behind whole rounds of config 0 (pipeline.hip resid_all) */ \
+                if constexpr (EPI == EPI_STORE || EPI == EPI_RESID_SCALE)                \
+                    gemm_launch_pp<T, 96, 256, 1, 8, AMODE, EPI>(p, stream);              \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the 96-row tile takes store / residual epilogues only"); \
+                break;                                                                    \
+            case 8: /* the same, three ring slots: two slabs in flight behind a short tile's few MFMAs */ \
+                if constexpr (EPI == EPI_STORE || EPI == EPI_RESID_SCALE)                \
+                    gemm_launch_ring<T, 128, 256, 2, 4, 3, AMODE, EPI>(p, stream);        \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the 128-row ring tile takes store / residual epilogues only"); \
+                break;                                                                    \
             case 6:                                                                       \
                 if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \
                     gemm_launch_8ph<T, EPI>(p, stream);                                   \

@@ -5,6 +5,7 @@
 //   - conv stages: NHWC; 16-bit operands of 3x3 convs carry a 1-pixel zero border
 //     ([B][H+2][W+2][C]) so the implicit-GEMM loader needs no bounds checks, residual paths
 //     stay f32 ([B*H*W][C]).
+#include <algorithm>
 #include <memory>
 
 #include "model.h"
@@ -345,6 +346,43 @@ struct MergedVit {
         segs.w1 = w1, segs.b1 = b1, segs.w2 = w2, segs.b2 = b2;
     }
 
+    // Whole rounds + a short tail.  A persistent 256x256 launch runs ceil(tiles / 256) rounds, and at one image the last
+    // round of fc1 (1360 tiles: 5.31 rounds) and of proj / fc2 (340 tiles: 1.33 rounds) is a third full.  The main loops
+    // are bound by what a CU can stage into LDS per slab ((BM + BN) x 128 bytes at ~50 GB/s per CU), not by the MFMAs,
+    // so a 96x256 tile costs 0.69 of a 256x256 tile's main loop and 0.375 of its epilogue: when the last round is at
+    // most half full, its rows run as a SECOND launch of 96-row tiles (tile config 7; <= 256 of them, one short round
+    // in which every workgroup has a tile) behind the whole rounds.  The rows of the second launch all belong to the
+    // last row segment.  Results are bit-identical (same K order per output element).  Measured at one image, FOV head:
+    // proj 93.7 -> 82.7 us, fc2 211.7 -> 207.7 us stand-alone (profiles/r03_tail_tile_ab.txt); in the step, same box,
+    // alternating runs: 25.17 ms (off) -> 24.90 (proj / fc2 split) -> 24.70 (fc1 too).  ME_GEMM_TAIL96=0 turns it off.
+    bool launch_with_short_tail(const GemmParams& p, EpiKind epi, const void* w1, const float* b1, const float* g1,
+                                const void* w2, const float* b2, const float* g2) {
+        static const bool enabled = !(getenv("ME_GEMM_TAIL96") && atoi(getenv("ME_GEMM_TAIL96")) == 0);
+        if (!enabled || p.N % 256 || p.M % 256 || p.K < 128) return false;
+        const int64_t nbn = p.N / 256;
+        if (256 % nbn) return false;
+        const int64_t per_round = 256 / nbn, row_tiles = p.M / 256;      // row tiles per round of 256 workgroups
+        const int64_t rounds = row_tiles / per_round, rem = row_tiles % per_round;
+        const int64_t rows1 = rounds * per_round * 256, rows2 = p.M - rows1;
+        const int64_t last_seg = p.seg2 ? p.seg2 : p.seg1;
+        if (rounds < 1 || rem == 0 || 2 * rem > per_round || cdiv(rows2, 96) * nbn > 256 || rows1 < last_seg) return false;
+        GemmParams a = p, b = p;
+        a.M = (int)rows1;
+        a.flop_rows = (int)std::min<int64_t>(real_rows(), rows1);
+        b.M = (int)rows2;
+        b.flop_rows = (int)std::max<int64_t>(0, real_rows() - rows1);
+        b.A = (const char*)p.A + rows1 * p.lda * 2;
+        if (p.out16) b.out16 = (char*)p.out16 + rows1 * p.ldc * 2;
+        if (p.out32) b.out32 = p.out32 + rows1 * p.ldc;
+        if (p.res32) b.res32 = p.res32 + rows1 * p.ldc;
+        b.seg1 = b.seg2 = 0;  // one weight set: the last segment's
+        if (p.seg2) b.W = w2, b.bias = b2, b.gamma = g2;
+        else if (p.seg1) b.W = w1, b.bias = b1, b.gamma = g1;
+        gemm_launch(a, A_PLAIN, epi, ctx->dtype, s, 0);
+        gemm_launch(b, A_PLAIN, epi, ctx->dtype, s, 7);
+        return true;
+    }
+
     // one GEMM over all segments (three weight sets): 16-bit output (qkv, fc1) ...
     void gemm_all(const void* A, int K, const void* w0, const void* w1, const void* w2, const float* b0,
                   const float* b1, const float* b2, int N, void* out16, int act) {
@@ -353,6 +391,9 @@ struct MergedVit {
         p.flop_rows = (int)real_rows();
         p.out16 = out16, p.ldc = N, p.act = act;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = b1, p.W_s2 = w2, p.bias_s2 = b2;
+        // fc1 at one image: five whole rounds + 224 short tiles instead of a sixth round a third full (qkv's 1020 tiles
+        // are 3.98 rounds and N = 3072 does not divide the round: launch_with_short_tail declines)
+        if (ctx->C() >= 256 && launch_with_short_tail(p, EPI_STORE, w1, b1, nullptr, w2, b2, nullptr)) return;
         gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
     }
     // ... or the residual update x += gamma * (A W^T + b) (proj, fc2).  On the two-group 256x256 tile: the
@@ -374,6 +415,7 @@ struct MergedVit {
         static const bool use_pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const bool pp = C >= 256 && K >= 128;
         const bool pp192 = pp && K <= 1024 && use_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
+        if (pp && !pp192 && launch_with_short_tail(p, EPI_RESID_SCALE, w1, bb1, g1, w2, bb2, g2)) return;
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, pp192 ? 5 : (pp ? 0 : -1));
     }
 

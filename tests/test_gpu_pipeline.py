@@ -546,6 +546,37 @@ def test_full_size_batch_equals_loop_of_batch_one():
     assert not np.array_equal(both[0], both[1]) and np.isfinite(both).all()
 
 
+_TAIL_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import matrix_eyes_amd as m
+from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+cfg = m.ModelConfig()
+ctx = m.Context(0, "f16", cfg)
+ctx.load_state_dict(synthetic_checkpoint(cfg))
+d, fov = ctx.extract_depth(synthetic_images(1, cfg.img_size, "structured", seed=5), None, want_fov=True)
+np.save(sys.argv[2], d)
+"""
+
+
+def test_short_tail_launches_change_no_bit(tmp_path):
+    """pipeline.hip launch_with_short_tail: at one image the last, third-full round of fc1 / proj / fc2 runs as a second
+    launch of 96x256 tiles over the remaining rows.  Same K order per output element, so the full-size depth is bit
+    for bit that of the single-launch form (ME_GEMM_TAIL96=0)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("split", {}), ("single", {"ME_GEMM_TAIL96": "0"})):
+        path = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _TAIL_CHILD, root, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
 def test_reconstruction_end_to_end_with_pt_checkpoint(tmp_path):
     """reconstruction.rs:155-205 through the host mirror: photo file + PyTorch .pt checkpoint in,
     depth-map PNG / stereogram PNG / OBJ+MTL out"""
