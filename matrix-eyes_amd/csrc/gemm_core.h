@@ -395,8 +395,11 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
 // after the row set-up settles them for good (cost: what is left of one L2 load latency, once per tile).
 // after_loads(): called once the per-lane constant loads have been issued (the tile queue draws its
 // ticket there, beside them)
+// TILE2D (the halo convolution kernel below): the tile is a 16 x 16 block of output pixels instead of 256
+// consecutive rows -- m0 is then the TILE index (image-major, tile rows, tile columns) and row t of the tile is pixel
+// (t >> 4, t & 15) of it; everything downstream sees the pixel's linear row index and coordinates as before.
 template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool PIN_CONSTS = false,
-          typename Hook = NoHook, int OUT8 = 0>
+          typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
                                               int wm, int wn, int lane, char* epi_lds,
                                               Hook after_loads = Hook()) {
@@ -472,7 +475,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         EpiRow row;
         row.m = m0 + wm * TM + r0;
         row.b = row.y = row.x = 0;
-        const bool pix = EPI == EPI_CONVT || (EPI == EPI_STORE && p.out16_border);
+        [[maybe_unused]] int t2_b = 0, t2_y0 = 0, t2_x0 = 0, t2_row = wm * TM + r0;  // TILE2D: tile origin, row in tile
+        if constexpr (TILE2D) {
+            const int tx = p.out_W >> 4, ty = p.out_H >> 4;
+            t2_b = m0 / (tx * ty);
+            const int rem = m0 - t2_b * (tx * ty);
+            t2_y0 = (rem / tx) * 16;
+            t2_x0 = (rem - (rem / tx) * tx) * 16;
+            row.b = t2_b, row.y = t2_y0 + (t2_row >> 4), row.x = t2_x0 + (t2_row & 15);
+            row.m = (row.b * p.out_H + row.y) * p.out_W + row.x;
+        }
+        const bool pix = !TILE2D && (EPI == EPI_CONVT || (EPI == EPI_STORE && p.out16_border));
         if (pix) {  // one pair of divisions per lane; afterwards the pixel walks with the row
             const int ppi = p.out_H * p.out_W;
             const int mm = row.m < p.M ? row.m : p.M - 1;
@@ -528,7 +541,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     if (row.m < p.M && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16);
-                    row.m += RPI;
+                    if constexpr (TILE2D) {
+                        t2_row += RPI;
+                        row.y = t2_y0 + (t2_row >> 4), row.x = t2_x0 + (t2_row & 15);
+                        row.m = (t2_b * p.out_H + row.y) * p.out_W + row.x;
+                    } else {
+                        row.m += RPI;
+                    }
                     if (pix) {
                         row.x += RPI;
                         while (row.x >= p.out_W) {
@@ -1357,6 +1376,253 @@ void gemm_launch_8ph(const GemmParams& p, hipStream_t stream) {
     ME_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 convolution (stride 1) with the activation tile staged ONCE per 64 input channels: "halo" form of the
+// two-group kernel.
+//
+// What bounds the kernels above is what a CU can stage into LDS per K slab: (BM + BN) x 128 bytes through the
+// LDS-DMA path at ~50 GB/s per CU -- 64 KiB per slab for the 256x256 tile, next to 2048 matrix-pipe cycles.  The
+// implicit-GEMM convolution stages the same activation pixels nine times, once per tap.  Here the M tile is a 16 x 16
+// block of output pixels; for each 64-channel slab of the input its 18 x 18 halo (324 pixels x 128 bytes = 41 KiB)
+// is staged once and the nine taps read it at shifted rows: per K slab 32 KiB of weights + 4.6 KiB of activations
+// instead of 64 KiB, and nothing but the weights (L2-resident) is fetched more than 1.27 times.
+//
+// K order: input-channel slab outermost, taps inside (the weights are packed [Cout][tap][Cin], so a slab is the 128
+// bytes at (tap * Cin + c * 64) * 2 of a weight row).  LDS: two halo slots of 328 rows + two weight slots of 256 rows
+// (148 KiB); the halo image is [pixel hy * 18 + hx][64 channels] with chunk c of a pixel at slot c ^ ((hx >> 1) & 7), so
+// the B-operand fragment of output row ty, tap (ky, kx) is the 16 consecutive rows (ty + ky) * 18 + kx + (0..15).
+// Roles: group 0 (waves 0-3) stages the weight rows of slab s+1 at the top of slab s; group 1 (waves 4-7, priority 1)
+// computes first and stages, mid-slab, two pieces per wave of the NEXT channel slab's halo during taps 0-5 (48 pieces
+// for the 41 needed), retired by its vmcnt(0) at the end of tap 8.  One barrier per slab.
+// Requires KH = KW = 3, stride 1, out_H and out_W multiples of 16, Cin a multiple of 64, N a multiple of 4.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
+    constexpr int BN = 256, HW = 4, WN = 4;
+    constexpr int TM = 128, TN = 64, MI = 8, NI = 4;
+    constexpr int HALO_ROWS = 328, HALO_BYTES = HALO_ROWS * 128, HALO_PIECES = HALO_ROWS / 8;  // 41
+    constexpr int W_BYTES = BN * 128, W_BASE = 2 * HALO_BYTES;
+    constexpr int B_IT = (BN / 8) / HW;  // 8 weight pieces per wave of group 0 per slab
+    constexpr int MI_CH = 2;
+    constexpr int SCR = 16 * MI_CH * (TN * 4);  // 8 KiB of epilogue scratch per wave
+    static_assert(HW * SCR <= HALO_BYTES && HW * SCR <= W_BYTES, "epilogue scratch exceeds a slot");
+    typedef typename MfmaOp<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2, gw = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = p.out_W >> 4, tiles_y = p.out_H >> 4;
+    const int mtiles = (p.M >> 8);                       // 16 x 16 pixel tiles (M = B * out_H * out_W)
+    const int nbn = (p.N + BN - 1) / BN;
+    const int ntiles = mtiles * nbn;
+    const int nc = p.Cin / 64;                            // channel slabs; nine taps each
+    const int srow = lane >> 3, sslot = lane & 7;
+
+    struct Tile {
+        int mt, n0;             // pixel-tile index, first output channel
+        const char* a;          // uniform: bordered input pixel (y0, x0) of the tile's image = halo pixel (0, 0)
+        const char* w;          // uniform: weight row n0
+        unsigned wo[B_IT];      // group 0: per-lane byte offsets of its weight pieces
+    };
+    auto setup = [&](Tile& t, int vb) {
+        // the super-row / XCD walk of tile_origin over (pixel tiles) x (column tiles)
+        GemmParams q = p;
+        int m0;
+        tile_origin<256, BN>(q, vb, ntiles, m0, t.n0);
+        t.mt = m0 >> 8;
+        const int b = t.mt / (tiles_x * tiles_y);
+        const int rem = t.mt - b * (tiles_x * tiles_y);
+        const int y0 = (rem / tiles_x) * 16, x0 = (rem - (rem / tiles_x) * tiles_x) * 16;
+        t.a = (const char*)p.A + (((int64_t)b * p.in_Hp + y0) * p.in_Wp + x0) * p.Cin * 2;
+        t.w = (const char*)p.W + (int64_t)t.n0 * p.K * 2;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = (i * HW + gw) * 8 + srow;
+            const int chunk = sslot ^ ((row >> 1) & 7);
+            int gn = t.n0 + row;
+            gn = gn < p.N ? gn : p.N - 1;
+            t.wo[i] = (unsigned)((int64_t)(gn - t.n0) * p.K * 2) + chunk * 16;
+        }
+    };
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    // weight rows of slab (c, tap) into weight slot `slot` (group 0)
+    auto stage_w = [&](const Tile& t, int c, int tap, int slot) {
+        const char* base = uniform_ptr(t.w + ((int64_t)tap * p.Cin + c * 64) * 2);
+        const unsigned dst = smem_base + W_BASE + slot * W_BYTES + gw * 1024;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16_raw(base, t.wo[i], dst + i * (HW * 1024));
+    };
+    // halo piece `pc` (8 pixels) of channel slab c into halo slot `slot` (group 1)
+    auto stage_halo_piece = [&](const Tile& t, int c, int pc, int slot) {
+        int r = pc * 8 + srow;
+        r = r < 324 ? r : 323;                              // the 4 pad rows repeat the last pixel (never read)
+        const int hy = (r * 3641) >> 16;                    // r / 18 for r < 324
+        const int hx = r - hy * 18;
+        const int chunk = sslot ^ ((hx >> 1) & 7);          // the halo image's swizzle goes by the pixel's COLUMN
+        const unsigned off = (unsigned)(((hy * p.in_Wp + hx) * p.Cin + c * 64) * 2 + chunk * 16);
+        glds16_raw(uniform_ptr(t.a), off, smem_base + slot * HALO_BYTES + pc * 1024);
+    };
+
+    // fragment addressing
+    const int frow = lane & 15, q4 = lane >> 4;
+    const int fswz = frow >> 1;
+    const int wslot0 = (q4 ^ fswz) * 16, wslot1 = ((q4 + 4) ^ fswz) * 16;
+    const int w_rd = (wn * TN + frow) * 128;
+    // A fragment of output row ty, tap (ky, kx), k-substep kk: halo row (ty + ky) * 18 + kx + frow, chunk (q4 + 4 kk) ^
+    // swizzle -- and the halo image swizzles by the pixel's column hx = kx + frow alone (the row parity that decides
+    // the bank half is hx & 1 too, 18 being even), so the lane's byte offset is (ty + ky) * 2304 + a_col[kx] (^ 64 for
+    // the second k-substep): three per-lane constants, the rest immediates
+    int a_col[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int hx = kx + frow;
+        a_col[kx] = hx * 128 + ((q4 ^ ((hx >> 1) & 7)) << 4);
+    }
+
+    if (group == 1) __builtin_amdgcn_s_setprio(1);
+    int vb = blockIdx.x;
+    Tile cur, nxt;
+    setup(cur, vb);
+    int next_vb = vb + (int)gridDim.x;
+    // prologue: halo of channel slab 0 (group 1: 11 pieces per wave cover 41) and weight slab (0, tap 0) (group 0)
+    if (group == 0) {
+        stage_w(cur, 0, 0, 0);
+    } else {
+        for (int k = 0; k < 11; ++k) {
+            const int pc = k * 4 + gw;
+            if (pc < HALO_PIECES) stage_halo_piece(cur, 0, pc, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int ws = 0, hs = 0;  // weight slot of the slab being consumed, halo slot of its channel slab
+
+    while (true) {
+        const bool has_next = next_vb < ntiles;
+        if (has_next) setup(nxt, next_vb);
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < nc; ++c) {
+            // who comes after this channel slab: the next one of this tile, the first of the next tile, or nobody
+            const bool next_c_here = c + 1 < nc;
+            const bool halo_follows = next_c_here || has_next;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < 9; ++tap) {
+                // ---- top of the slab: group 0 stages the weights of the slab after this one
+                if (group == 0) {
+                    if (tap < 8)
+                        stage_w(cur, c, tap + 1, ws ^ 1);
+                    else if (next_c_here)
+                        stage_w(cur, c + 1, 0, ws ^ 1);
+                    else if (has_next)
+                        stage_w(nxt, 0, 0, ws ^ 1);
+                }
+                const char* sw = smem + W_BASE + ws * W_BYTES + w_rd;
+                const char* sa = smem + hs * HALO_BYTES;
+                const char* sa_tap = sa + (wm * 8 + ky) * (18 * 128);
+                const int a0 = kx == 0 ? a_col[0] : (kx == 1 ? a_col[1] : a_col[2]);
+                const int a1 = a0 ^ 64;
+                constexpr int G = 2 * MI;
+                frag af[G], wf[2][NI];
+                auto rd_a = [&](int g) {
+                    return *reinterpret_cast<const frag*>(sa_tap + (g < MI ? a0 : a1) + (g % MI) * (18 * 128));
+                };
+                auto rd_w = [&](int kk, int j) {
+                    return *reinterpret_cast<const frag*>(sw + j * 2048 + (kk == 0 ? wslot0 : wslot1));
+                };
+                // ---- first k-substep: the fragment feed of the two-group kernel (A fragment two groups ahead, the
+                // second substep's weight fragments early on), pinned
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[0][j] = rd_w(0, j);
+                af[0] = rd_a(0);
+                af[1] = rd_a(1);
+#pragma unroll
+                for (int g = 0; g < MI; ++g) {
+                    if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+                    if (g < NI) wf[1][g] = rd_w(1, g);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[g % MI][j] = MfmaOp<T>::run(wf[0][j], af[g], acc[g % MI][j]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, NI + 2, 0);
+                SchedPin<MI, NI, 0>::template run<0>();
+                // ---- mid-slab: group 1 stages two pieces of the next channel slab's halo (taps 0 .. 5)
+                if (group == 1 && halo_follows && tap < 6) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int pc = tap * 8 + gw * 2 + k;
+                        if (pc < HALO_PIECES) {
+                            if (next_c_here) stage_halo_piece(cur, c + 1, pc, hs ^ 1);
+                            else stage_halo_piece(nxt, 0, pc, hs ^ 1);
+                        }
+                    }
+                }
+                // ---- second k-substep
+#pragma unroll
+                for (int g = MI; g < G; ++g) {
+                    if (g + 2 < G) af[g + 2] = rd_a(g + 2);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[g % MI][j] = MfmaOp<T>::run(wf[1][j], af[g], acc[g % MI][j]);
+                }
+                SchedPin<MI, NI, 0>::template run<0>();
+                // ---- close the slab: group 0's weights of the next slab have landed; group 1's halo pieces must have
+                // landed before the first slab that reads them (the one after tap 8)
+                if (group == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                ws ^= 1;
+                if (++kx == 3) kx = 0, ++ky;
+            }
+            hs ^= 1;
+        }
+        // ws / hs now name the next tile's first weight slab / halo; the slots consumed last are the scratch
+        {
+            char* scr = (group == 0 ? smem + (hs ^ 1) * HALO_BYTES : smem + W_BASE + (ws ^ 1) * W_BYTES) + gw * SCR;
+            gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true, NoHook, 0, true>(p, acc, cur.mt, cur.n0, wm, wn, lane, scr);
+        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the scratch slots are restaged by the next tile's first slab
+        asm volatile("" ::: "memory");
+        cur = nxt;
+        vb = next_vb;
+        next_vb = vb + (int)gridDim.x;
+    }
+}
+
+template <typename T, int EPI>
+void conv_halo_launch(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = 2 * 328 * 128 + 2 * 256 * 128;
+    ME_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out_H % 16 == 0 && p.out_W % 16 == 0 && p.Cin % 64 == 0 &&
+                 p.M % 256 == 0,
+             ME_ERR_BAD_SHAPE, "conv (halo tile): %dx%d stride %d on %dx%d, Cin %d", p.KH, p.KW, p.stride, p.out_H, p.out_W,
+             p.Cin);
+    auto kern = conv_halo_kernel<T, EPI>;
+    static PerDeviceOnce once;
+    const int resident = per_device_once(once, [&](int dev) {
+        ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int per_cu = 0, cus = 0;
+        ME_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, smem));
+        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int r = (per_cu < 1 ? 1 : per_cu) * cus;
+        r -= r % 8;
+        return r < 8 ? 8 : r;
+    });
+    const int64_t ntiles = (int64_t)(p.M / 256) * cdiv(p.N, 256);
+    ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "conv grid %lld out of range", (long long)ntiles);
+    const int64_t grid = ntiles < resident ? ntiles : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
+    ME_HIP(hipGetLastError());
+}
+
 // vmcnt(rem * P) for a run-time rem in [0, R]
 template <int R, int P>
 struct WaitSlabs {
@@ -1546,6 +1812,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
                     gemm_launch_ring<T, 128, 256, 2, 4, 3, AMODE, EPI>(p, stream);        \
                 else                                                                      \
                     fail(ME_ERR_BAD_ARG, "gemm: the 128-row ring tile takes store / residual epilogues only"); \
+                break;                                                                    \
+            case 9:                                                                       \
+                if constexpr (AMODE == A_CONV && EPI == EPI_STORE)                        \
+                    conv_halo_launch<T, EPI>(p, stream);                                  \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
                 break;                                                                    \
             case 6:                                                                       \
                 if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \

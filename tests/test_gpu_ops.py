@@ -98,7 +98,7 @@ def test_linear_random_shapes():
         M = rnd.choice([1, 2, 7, 63, 64, 65, 127, 129, 255, 257, 300, 511, 513, 777, rnd.randrange(1, 1500)])
         N = 4 * rnd.choice([1, 2, 3, 7, 8, 15, 16, 31, 33, 64, 65, rnd.randrange(1, 160)])
         K = 64 * rnd.choice([1, 2, 3, 4, 5, 9, 16])
-        cfg = rnd.randrange(-1, ncfg)
+        cfg = rnd.randrange(-1, min(ncfg, 9))      # every configuration that takes a plain linear (9 is the conv halo tile)
         g = torch.Generator().manual_seed(it)
         a = dev16(torch.randn(M, K, generator=g), "f16")
         w = dev16(torch.randn(N, K, generator=g) / math.sqrt(K), "f16")
@@ -294,6 +294,58 @@ def test_conv2d(dtype, case, cfg):
     assert float(out16[:, -1].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=48, W=32, Cin=64, Cout=256),
+    dict(B=1, H=32, W=64, Cin=256, Cout=512, res=True, relu=True),
+    dict(B=1, H=16, W=16, Cin=128, Cout=256, relu=True),
+    dict(B=1, H=272, W=272, Cin=128, Cout=256, res=True),       # 289 pixel tiles: workgroups walk on to a second tile
+    dict(B=3, H=96, W=112, Cin=192, Cout=256, res=True, relu=True),
+])
+def test_conv3x3_halo_tile(dtype, case):
+    """Tile config 9 (gemm_core.h conv_halo_kernel): 16 x 16 pixel tiles whose 18 x 18 halo is staged once per 64 input
+    channels and read at shifted rows by the nine taps -- against torch.nn.functional.conv2d on the same 16-bit operands,
+    with the f32 residual inputs, the fused ReLU, the zero-bordered 16-bit output and the split [hi | lo] output form;
+    maps larger than one round of tiles; the zero border stays zero.  The automatic choice picks it for such shapes."""
+    ctx = ctx_for("tiny", dtype)
+    B, H, W, Cin, Cout = (case[n] for n in ("B", "H", "W", "Cin", "Cout"))
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    xb, w16, bias_d = bordered(x, dtype), dev16(pack_conv(w), dtype), bias.cuda()
+    res = torch.randn(B * H * W, Cout, generator=g).cuda() if case.get("res") else None
+    res2 = torch.randn(B * H * W, Cout, generator=g).cuda() if case.get("res") else None
+    act = 2 if case.get("relu") else 0
+    x16 = xb[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).double().cpu()
+    ref = F.conv2d(x16, dev16(w, dtype).double().cpu(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    if res is not None:
+        ref = ref + res.double().cpu() + res2.double().cpu()
+    ref16 = F.relu(ref) if act else ref
+    outs = {}
+    for cfg in (9, -1, 0):
+        out32 = torch.empty(B * H * W, Cout, dtype=torch.float32, device="cuda")
+        out16 = torch.zeros(B, H + 2, W + 2, Cout, dtype=TORCH16[dtype], device="cuda")
+        torch.cuda.synchronize()
+        _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, 3, 1, ptr(bias_d), ptr(res), ptr(res2),
+                                         ptr(out32), ptr(out16), 1, act, 0, cfg))
+        ctx.synchronize()
+        assert max_abs_rel(out32.cpu(), ref) < 3e-5, cfg
+        got16 = out16[:, 1:H + 1, 1:W + 1, :].reshape(B * H * W, Cout).float().cpu()
+        assert max_abs_rel(got16, ref16) < 6 * OUT_EPS[dtype] * 4, cfg
+        assert float(out16[:, 0].abs().max()) == 0 and float(out16[:, :, 0].abs().max()) == 0
+        assert float(out16[:, -1].abs().max()) == 0 and float(out16[:, :, -1].abs().max()) == 0
+        outs[cfg] = (out32, out16)
+    # a repeated launch of the halo tile reproduces itself bit for bit
+    out32 = torch.empty_like(outs[9][0])
+    out16 = torch.zeros_like(outs[9][1])
+    torch.cuda.synchronize()
+    _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, 3, 1, ptr(bias_d), ptr(res), ptr(res2),
+                                     ptr(out32), ptr(out16), 1, act, 0, 9))
+    ctx.synchronize()
+    assert torch.equal(out32, outs[9][0]) and torch.equal(out16, outs[9][1])
+
+
 def test_conv2d_random_shapes():
     """40 random convolutions: non-square and odd maps, 1x1 and 3x3, stride 1 and 2, any tile configuration, with
     and without the two f32 residual inputs and the fused ReLU -- against torch.nn.functional.conv2d on the same
@@ -308,7 +360,7 @@ def test_conv2d_random_shapes():
         B = rnd.choice([1, 1, 2, 3])
         H, W = (2 * rnd.randrange(1, 14), 2 * rnd.randrange(1, 14)) if s == 2 else (rnd.randrange(1, 27), rnd.randrange(1, 27))
         Cin, Cout = 64 * rnd.choice([1, 2, 3, 4]), 4 * rnd.choice([1, 2, 8, 9, 16, 33, 64])
-        cfg = rnd.randrange(-1, ncfg)
+        cfg = rnd.choice([-1, 0, 1, 2, 3, 4, 5, 7, 8])      # 6 is linear-only, 9 the halo tile (its own test below)
         with_res, relu = rnd.random() < 0.5, rnd.random() < 0.5
         g = torch.Generator().manual_seed(1000 + it)
         x = torch.randn(B, Cin, H, W, generator=g)
