@@ -57,6 +57,7 @@ pub struct MeModelConfig {
     pub ln_eps: f32,
     pub align_corners: i32,
     pub split_operands: i32,
+    pub fp8_linears: i32,
 }
 #[repr(C)]
 pub struct MeCtx {

@@ -27,7 +27,7 @@ class CModelConfig(C.Structure):
         ("grid", C.c_int32), ("embed_dim", C.c_int32), ("num_heads", C.c_int32),
         ("depth", C.c_int32), ("tap_blocks", C.c_int32 * 2), ("enc_dims", C.c_int32 * 4),
         ("dec_dim", C.c_int32), ("head_dims", C.c_int32 * 2), ("ln_eps", C.c_float),
-        ("align_corners", C.c_int32), ("split_operands", C.c_int32),
+        ("align_corners", C.c_int32), ("split_operands", C.c_int32), ("fp8_linears", C.c_int32),
     ]
 
 

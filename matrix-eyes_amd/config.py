@@ -20,6 +20,7 @@ class ModelConfig:
     ln_eps: float = 1e-5                # Burn LayerNormConfig default
     align_corners: bool = True          # Burn bilinear
     split_operands: int = 3             # me_model_config.split_operands: hi + lo operand stages (bit mask)
+    fp8_linears: int = 0                # me_model_config.fp8_linears: fp8 contexts, which linears run on fp8 (0 = default)
 
     @property
     def window(self) -> int:
@@ -44,6 +45,7 @@ class ModelConfig:
         c.ln_eps = self.ln_eps
         c.align_corners = 1 if self.align_corners else 0
         c.split_operands = self.split_operands
+        c.fp8_linears = self.fp8_linears
         return c
 
     @staticmethod

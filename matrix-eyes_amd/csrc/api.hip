@@ -111,6 +111,7 @@ int32_t me_default_config(me_model_config* cfg) {
     cfg->ln_eps = 1e-5f;
     cfg->align_corners = 1;
     cfg->split_operands = 3;
+    cfg->fp8_linears = 0;
     return ME_OK;
 }
 
@@ -151,6 +152,12 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         ME_CHECK(!ctx->fp8 || ctx->cfg.embed_dim % 256 == 0, ME_ERR_BAD_SHAPE,
                  "ME_DTYPE_FP8 needs embed_dim a multiple of 256 (256x256 tiles, K slabs of 128): %d", ctx->cfg.embed_dim);
         ctx->split_mask = ctx->cfg.split_operands;  // model.h SplitStage bits
+        if (const char* e = getenv("ME_FP8_LINEARS")) {     // diagnostic override of the default (tools/fp8_budget.py)
+            if (!cfg || cfg->fp8_linears == 0) ctx->cfg.fp8_linears = atoi(e);
+        }
+        ME_CHECK(ctx->cfg.fp8_linears >= 0 && ctx->cfg.fp8_linears <= 15, ME_ERR_BAD_ARG, "fp8_linears %d not in [0, 15]",
+                 ctx->cfg.fp8_linears);
+        ctx->fp8_mask = ctx->fp8 ? (ctx->cfg.fp8_linears ? ctx->cfg.fp8_linears : ME_FP8_LINEARS_DEFAULT) : 0;
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;

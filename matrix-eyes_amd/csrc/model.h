@@ -107,6 +107,9 @@ struct me_ctx {
     // ME_DTYPE_FP8 (BASELINE configs[3]): `dtype` is ME_DTYPE_F16 for every 16-bit operand, and the qkv / fc1 /
     // fc2 linears of the three ViTs run on MX block-scaled fp8 (gemm_fp8.hip)
     bool fp8 = false;
+    // which linears of a block run on fp8 in an ME_DTYPE_FP8 context: 1 = qkv, 2 = proj, 4 = fc1, 8 = fc2
+    // (me_model_config.fp8_linears; 0 there means all four)
+    int32_t fp8_mask = 0;
     char* arena8 = nullptr;  // the fp8 weight copies (derived data: rebuilt after finalize / adopt / broadcast)
     size_t arena8_bytes = 0;
     // Stages whose 16-bit activation operands are carried as hi + lo pairs (me::SplitStage bits)

@@ -421,7 +421,7 @@ struct MergedVit {
 
     // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales
     void gemm8(const void* A8, const uint8_t* As, int K, int N, const VitBlockW& b0, const VitBlockW& b1,
-               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2, 3 proj*/) {
+               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2, 3 proj*/, bool hid16_out = false) {
         GemmParams p = base_params();
         auto w8 = [&](const VitBlockW& b) { return which == 0 ? b.qkv_w8 : (which == 1 ? b.fc1_w8 : (which == 2 ? b.fc2_w8 : b.proj_w8)); };
         auto ws = [&](const VitBlockW& b) { return which == 0 ? b.qkv_ws : (which == 1 ? b.fc1_ws : (which == 2 ? b.fc2_ws : b.proj_ws)); };
@@ -437,7 +437,9 @@ struct MergedVit {
             p.out16 = qkv;
             gemm_fp8_launch(p, EPI_STORE, s);
         } else if (which == 1) {
-            p.act = ACT_GELU, p.out8 = (uint8_t*)hid, p.out8_scale = hid_s, p.out8_mt = (int)(Rtot / 128);
+            p.act = ACT_GELU;
+            if (hid16_out) p.out16 = hid;  // fc2 stays 16-bit: the hidden layer leaves as f16
+            else p.out8 = (uint8_t*)hid, p.out8_scale = hid_s, p.out8_mt = (int)(Rtot / 128);
             gemm_fp8_launch(p, EPI_STORE, s);
         } else {
             p.gamma = gamma(b0), p.gamma_s1 = gamma(b1), p.gamma_s2 = gamma(b2), p.res32 = tok, p.out32 = tok;
@@ -450,27 +452,55 @@ struct MergedVit {
         const VitBlockW &b0 = p0.blocks[i], &b1 = p1.blocks[i], &b2 = p2.blocks[i];  // by physical segment
         const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
         if (ctx->fp8) {
-            // BASELINE configs[3]: LayerNorm writes MX fp8, the four linears run on the scaled fp8 MFMA; attention
-            // itself stays f16 (q, k, v and its output are 16-bit; the output is quantised for the projection)
+            // BASELINE configs[3]: the linears named by me_model_config.fp8_linears (default: all four) run on the scaled
+            // fp8 MFMA, each fed by a producer that writes MX fp8 -- LayerNorm (qkv, fc1), the attention kernel's own
+            // store stage (proj), fc1's epilogue (fc2) -- the others on the 16-bit kernels; attention itself stays f16
+            const int mask = ctx->fp8_mask;
+            const bool q8 = mask & 1, p8 = mask & 2, f18 = mask & 4, f28 = mask & 8;
+            const int windows = W0 + W1 * (fov ? 2 : 1);
             set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
-            layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
-            gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
-            // the attention kernel writes the projection's fp8 operand itself (the bytes a separate
-            // quantize_f16_to_fp8 pass over its 16-bit output would give: ME_FP8_ATT_SEPARATE=1 runs that pass,
-            // the test compares the two)
-            static const bool separate = getenv("ME_FP8_ATT_SEPARATE") != nullptr;
-            if (separate || heads % 2) {
-                attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
-                quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
+            if (q8) {
+                layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
             } else {
-                attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs, att8, att_s,
-                                 Rtot / 128);
+                layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+                gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE);
             }
-            gemm8(att8, att_s, C, C, b0, b1, b2, 3);
+            if (p8) {
+                // the attention kernel writes the projection's fp8 operand itself (the bytes a separate
+                // quantize_f16_to_fp8 pass over its 16-bit output would give: ME_FP8_ATT_SEPARATE=1 runs that pass,
+                // the test compares the two)
+                static const bool separate = getenv("ME_FP8_ATT_SEPARATE") != nullptr;
+                if (separate || heads % 2) {
+                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs);
+                    quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
+                } else {
+                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, att8, att_s, Rtot / 128);
+                }
+                gemm8(att8, att_s, C, C, b0, b1, b2, 3);
+            } else {
+                attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs);
+                resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
+            }
             set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
-            layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
-            gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1);
-            gemm8(hid, hid_s, 4 * C, C, b0, b1, b2, 2);
+            if (f18) {
+                layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1, !f28);
+            } else {
+                layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+                gemm_all(xn, C, b0.fc1_w, b1.fc1_w, b2.fc1_w, b0.fc1_b, b1.fc1_b, b2.fc1_b, 4 * C, hid, ACT_GELU);
+            }
+            if (f28) {
+                const uint8_t* h8 = (const uint8_t*)hid;
+                if (!f18) {  // a 16-bit fc1 left f16: quantised here as fc2's operand
+                    uint8_t* q = (uint8_t*)site_buf(ctx, "vitm.hid8", (size_t)Rtot * 4 * C);
+                    quantize_f16_to_fp8_launch(hid, q, hid_s, Rtot, 4 * C, 0, s);
+                    h8 = q;
+                }
+                gemm8(h8, hid_s, 4 * C, C, b0, b1, b2, 2);
+            } else {
+                resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2);
+            }
             if (taps.fn) taps.fn(taps.user, i, tok + row_main * C);
             return;
         }

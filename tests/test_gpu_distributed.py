@@ -75,3 +75,30 @@ def test_two_ranks_share_one_packed_arena():
     want, want_fov = ctx.extract_depth(rgb, None, want_fov=True)
     for _, _, mine, depth, fov, _ in res:
         assert np.array_equal(depth, want[mine]) and np.array_equal(fov, want_fov[mine])
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the script starts its two ranks itself (child processes created
+    before anything touches the GPU), rank 0 builds the checkpoint, the packed arena reaches rank 1 by ONE broadcast,
+    both ranks time the same steps and rank 0 prints one JSON line with n_gpus 2, the aggregate rate and both ranks'
+    step times.  On this one-GPU box the ranks share the device, so torch.distributed runs on gloo (ME_DIST_BACKEND;
+    RCCL refuses two ranks on one device) -- the driver's multi-GPU runs take the same entry with the default, nccl."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ME_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=800, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    per_rank = d["config"]["per_rank_ms_per_step"]
+    assert len(per_rank) == 2 and all(v > 0 for v in per_rank)
+    assert abs(d["ms_per_step"] - max(per_rank)) / max(per_rank) < 0.25        # MAX over ranks (barrier skew aside)
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02     # two images per step, whole job
+    assert "gloo" in d["config"]["weights_broadcast"]

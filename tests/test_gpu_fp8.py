@@ -289,6 +289,32 @@ def test_extract_depth_fp8_small_model():
 
 
 @pytest.mark.parametrize("windows,tokens,heads", [(3, 577, 4), (5, 65, 2), (2, 130, 16), (1, 128, 2)])
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
+def test_fp8_linears_mask_small_model(mask):
+    """me_model_config.fp8_linears: any subset of {qkv, proj, fc1, fc2} on fp8, the rest on the 16-bit kernels with
+    16-bit operands between them (an f16 fc1 feeding an fp8 fc2 is quantised by a separate pass, an fp8 fc1 feeding an
+    f16 fc2 writes f16).  Every mask gives a finite depth closer to the f16 path than the all-fp8 path's bound, is
+    deterministic, and a batch equals the loop of batch one."""
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+    cfg = m.ModelConfig(grid=8, embed_dim=256, num_heads=4, depth=4, tap_blocks=(1, 2), enc_dims=(64, 128, 128, 128),
+                        dec_dim=256, head_dims=(32, 1), fp8_linears=mask)
+    w = synthetic_checkpoint(cfg)
+    rgb = synthetic_images(2, cfg.img_size)
+    f16 = m.Context(0, "f16", cfg)
+    f16.load_state_dict(w)
+    ref = f16.extract_depth(rgb, None)
+    f16.close()
+    ctx = m.Context(0, "fp8", cfg)
+    ctx.load_state_dict(w)
+    d = ctx.extract_depth(rgb, None)
+    assert np.isfinite(d).all() and np.array_equal(d, ctx.extract_depth(rgb, None))
+    assert np.array_equal(ctx.extract_depth(rgb[1:2], None)[0], d[1])
+    err = rel_l2(d, ref)
+    print("fp8_linears", mask, "rel-L2 against the f16 path", err)
+    assert 1e-4 < err < 0.1
+    ctx.close()
+
+
 def test_attention_fp8_output_equals_quantised_16bit_output(windows, tokens, heads):
     ctx = ctx_for("tiny", "f16")
     C, rows = heads * 64, windows * tokens
@@ -315,6 +341,7 @@ import matrix_eyes_amd as m
 from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
 cfg = m.ModelConfig(grid=8, embed_dim=256, num_heads=4, depth=4, tap_blocks=(1, 2), enc_dims=(64, 128, 128, 128),
                     dec_dim=256, head_dims=(32, 1))
+cfg.fp8_linears = 15          # proj on fp8 too: the attention kernel then writes the projection's fp8 operand
 ctx = m.Context(0, "fp8", cfg)
 ctx.load_state_dict(synthetic_checkpoint(cfg))
 d, fov = ctx.extract_depth(synthetic_images(2, cfg.img_size), None, want_fov=True)

@@ -60,8 +60,10 @@ def test_linear_gelu(dtype):
 def test_gelu_function(cfg):
     """The epilogue's GELU alone: identity weights and zero bias make the pre-activation the f16 input
     itself, so the outputs are gelu(x) for ~1 M inputs over [-9, 9], the f16 extremes and the denormals.
-    x * Phi(x) with the exact erf (burn activation::gelu, vit.rs:121): the f32 result within 2.5e-7 + one f32
-    rounding of the exact value, the 16-bit result (the fast path the ViT takes) within half an f16 code."""
+    x * Phi(x) with the exact erf (burn activation::gelu, vit.rs:121): the f32 result (degree-9 form) within 2.5e-7 +
+    one f32 rounding of the exact value; the 16-bit result -- the fast path the ViT takes, a degree-6 form accurate to
+    4.5e-5 relative / 6.5e-6 absolute, a tenth of an f16 code -- within 0.6 of an f16 code of the exact value, equal
+    to the correctly rounded value for all but the inputs that sit within that tenth of a rounding boundary."""
     M, N = 4096, 256
     ctx = ctx_for("tiny", "f16")
     g = torch.Generator().manual_seed(11)
@@ -82,8 +84,8 @@ def test_gelu_function(cfg):
     # 16-bit copy: the correctly rounded value, or its neighbour where the f32 result sits on a rounding boundary
     want16 = ref.half()
     ulp = (want16.double().abs() * 2.0 ** -10).clamp_min(2.0 ** -24)
-    assert bool(((out16.double() - ref).abs() <= 0.5 * ulp + 3e-7).all())
-    assert float((out16 != want16).float().mean()) < 1e-3
+    assert bool(((out16.double() - ref).abs() <= 0.6 * ulp + 7e-6).all())
+    assert float((out16 != want16).float().mean()) < 0.1
 
 
 def test_linear_random_shapes():

@@ -20,20 +20,36 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# TCC_HIT / TCC_MISS (round 3): where the operand over-fetch of FETCH_SIZE is served from -- L2 hit rate =
+# TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) (MI355X_MICROARCH.md, L2); a pass whose counters this rocprofv3 does not
+# know is skipped
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
-          ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
-DEFAULT = ["qkv:0", "fc1:0", "proj:0", "fc2:0", "conv768:0", "attn:0"]
+          ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
+          ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCC_REQ_sum", "TCC_EA0_RDREQ_sum"]]
+# the launches of one step at one image: whole rounds on tile config 0 + the short tail on config 7 (pipeline.hip
+# launch_with_short_tail) for fc1 / proj / fc2; the 3x3 convolutions on the halo tile (config 9)
+DEFAULT = ["qkv:0", "fc1:0", "fc1_tail:7", "proj:0", "proj_tail:7", "fc2:0", "fc2_tail:7", "conv768:9", "attn:0"]
 CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6",
-             5: "192x256x64/8w-pp"}
-PROBE_M = 21760   # tools/gemm_probe.py's default rows
-SHAPES = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
+             5: "192x256x64/8w-pp", 6: "256x256x64/8w-8ph", 7: "96x256x64/8w-pp", 8: "128x256x64/8w-ring3",
+             9: "16x16px-x256x64/8w-halo"}
+# op -> (gemm_probe.py op, N, K, rows): the rows each launch of the step works on
+SHAPES = {"qkv": ("qkv", 3072, 1024, 21760), "fc1": ("fc1", 4096, 1024, 20480), "fc1_tail": ("fc1", 4096, 1024, 1280),
+          "proj": ("proj", 1024, 1024, 16384), "proj_tail": ("proj", 1024, 1024, 5376),
+          "fc2": ("fc2", 1024, 4096, 16384), "fc2_tail": ("fc2", 1024, 4096, 5376)}
 SHAPES8 = {"qkv8": (3072, 1024), "fc1_8": (4096, 1024), "fc2_8": (1024, 4096)}   # MX fp8 operands
+PROBE_M = 21760
 
 
 def describe(op, cfg):
     """(kernel name as bench.py's profile reports it, algorithmic bytes per launch)"""
     if op in SHAPES:
-        n, k = SHAPES[op]
+        probe, n, k, rows = SHAPES[op]
+        resid = probe in ("proj", "fc2")
+        out = rows * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
+        bytes_ = rows * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
+        return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
+    if False:
+        n, k = 0, 0
         resid = op in ("proj", "fc2")
         out = PROBE_M * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
         bytes_ = PROBE_M * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
@@ -48,15 +64,19 @@ def describe(op, cfg):
         px = 768 * 768
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},conv,store>", 770 * 770 * 256 * 2 + 256 * 2304 * 2 + px * 256 * (4 + 4 + 2)
     return "attention_kernel", 35 * 577 * (3072 + 1024) * 2
-KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_kernel", "attention_kernel")
+KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_kernel", "gemm_8ph_kernel", "conv_halo_kernel",
+               "attention_kernel")
 
 
 def run_pass(op, cfg, counters, work):
     out = os.path.join(work, f"{op}_{'_'.join(counters)}"[:80])
+    probe, rows = (SHAPES[op][0], SHAPES[op][3]) if op in SHAPES else (op, PROBE_M)
     cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
-           "--", "python3", os.path.join(ROOT, "tools", "gemm_probe.py"), op, str(cfg), "6"]
-    subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+           "--", "python3", os.path.join(ROOT, "tools", "gemm_probe.py"), probe, str(cfg), "6"]
+    r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PROBE_M=str(rows)),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    if r.returncode != 0:     # e.g. a counter this rocprofv3 build does not list
+        return {}, None
     vals, durs = {}, []
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -90,6 +110,8 @@ def main():
         entry["duration_us_under_pmc"] = sum(durs) / max(1, len(durs))
         if "FETCH_SIZE" in entry and "WRITE_SIZE" in entry:
             entry["hbm_bytes"] = (2.0 * entry["FETCH_SIZE"] + entry["WRITE_SIZE"]) * 1024.0
+        if entry.get("TCC_HIT_sum") is not None and entry.get("TCC_MISS_sum") is not None:
+            entry["l2_hit_rate"] = entry["TCC_HIT_sum"] / max(1.0, entry["TCC_HIT_sum"] + entry["TCC_MISS_sum"])
         if entry.get("GRBM_GUI_ACTIVE"):
             gui = entry["GRBM_GUI_ACTIVE"] / 8.0
             entry["mfma_util"] = entry.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0)

@@ -21,7 +21,7 @@ t = time.time()
 inv, fov = O.extract_depth(img, None, w, oracle_cfg(cfg))
 print(f"oracle {time.time() - t:.1f} s", flush=True)
 for mask in masks:
-    os.environ["ME_SPLIT_OPERANDS"] = str(mask)
+    cfg = m.ModelConfig(**{**cfg.__dict__, "split_operands": mask})
     ctx = m.Context(0, dtype, cfg)
     ctx.load_state_dict(w)
     d, f = ctx.extract_depth(img.numpy(), None, want_fov=True)
