@@ -288,7 +288,6 @@ def test_extract_depth_fp8_small_model():
     assert np.abs(res["fp8"][1] - ref_fov.numpy()).max() < 2.0
 
 
-@pytest.mark.parametrize("windows,tokens,heads", [(3, 577, 4), (5, 65, 2), (2, 130, 16), (1, 128, 2)])
 @pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
 def test_fp8_linears_mask_small_model(mask):
     """me_model_config.fp8_linears: any subset of {qkv, proj, fc1, fc2} on fp8, the rest on the 16-bit kernels with
@@ -315,6 +314,7 @@ def test_fp8_linears_mask_small_model(mask):
     ctx.close()
 
 
+@pytest.mark.parametrize("windows,tokens,heads", [(3, 577, 4), (5, 65, 2), (2, 130, 16), (1, 128, 2)])
 def test_attention_fp8_output_equals_quantised_16bit_output(windows, tokens, heads):
     ctx = ctx_for("tiny", "f16")
     C, rows = heads * 64, windows * tokens
