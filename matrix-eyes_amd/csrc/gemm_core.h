@@ -175,32 +175,47 @@ __device__ __forceinline__ int64_t conv_pixel(const GemmParams& p, int gm) {
     const int x = rem - y * p.out_W;
     return ((int64_t)b * p.in_Hp + y * p.stride) * p.in_Wp + x * p.stride;
 }
-// Byte offset of K slab kt from a row's tap-(0,0) address.  Slabs are asked for in order (kt = 0 rewinds),
-// so the tap walk is three scalar counters instead of divisions.
+// K slab kt of the A operand (byte offset from a row's tap-(0,0) address) and of the weight rows.  A convolution's
+// K index is (tap, cin) in the packed weights, [Cout][tap][Cin], and its slabs are WALKED input-channel slab outermost,
+// taps inside: slab kt = (c, tap) with c = kt / taps.  Every convolution kernel uses this one order -- the halo tile
+// below must (it stages one channel slab's halo for its nine taps), and the other tiles follow so that a convolution's
+// f32 sums do not depend on the tile configuration the problem size happens to select (a batch equals a loop of
+// batch-one calls bit for bit).  Stateless: two multiplications by reciprocals instead of divisions.
 template <int AMODE>
 struct SlabWalk {
-    int cin_steps, pad, kc, ky, kx;
+    int pad, taps, kw, cin;
     __device__ __forceinline__ void init(const GemmParams& p) {
-        cin_steps = AMODE == A_CONV ? p.Cin / 64 : 1;
         pad = AMODE == A_CONV ? (p.KH - 1) / 2 : 0;
-        kc = ky = kx = 0;
+        taps = AMODE == A_CONV ? p.KH * p.KW : 1;
+        kw = AMODE == A_CONV ? p.KW : 1;
+        cin = p.Cin;
     }
-    __device__ __forceinline__ int64_t next(const GemmParams& p, int kt) {
+    // slab -> (c, tap): taps is 1 or 9 (KH = KW in {1, 3}); 7282 = ceil(2^16 / 9) is exact for kt < 32768
+    __device__ __forceinline__ void split(int kt, int& c, int& tap) const {
+        c = taps == 1 ? kt : (int)(((unsigned)kt * 7282u) >> 16);
+        tap = kt - c * taps;
+    }
+    __device__ __forceinline__ int64_t a_off(const GemmParams& p, int kt) const {
         if constexpr (AMODE == A_PLAIN) {
             return (int64_t)kt * 128;
         } else {
-            if (kt == 0) kc = ky = kx = 0;
-            const int64_t off = ((int64_t)(ky + 1 - pad) * p.in_Wp + (kx + 1 - pad)) * p.Cin * 2 + kc * 128;
-            if (++kc == cin_steps) {
-                kc = 0;
-                if (++kx == p.KW) {
-                    kx = 0;
-                    ++ky;
-                }
-            }
-            return off;
+            int c, tap;
+            split(kt, c, tap);
+            const int ky = kw == 1 ? 0 : (int)(((unsigned)tap * 21846u) >> 16);  // tap / 3
+            const int kx = tap - ky * kw;
+            return ((int64_t)(ky + 1 - pad) * p.in_Wp + (kx + 1 - pad)) * cin * 2 + c * 128;
         }
     }
+    __device__ __forceinline__ int64_t w_off(int kt) const {
+        if constexpr (AMODE == A_PLAIN) {
+            return (int64_t)kt * 128;
+        } else {
+            int c, tap;
+            split(kt, c, tap);
+            return ((int64_t)tap * cin + c * 64) * 2;
+        }
+    }
+    __device__ __forceinline__ int64_t next(const GemmParams& p, int kt) const { return a_off(p, kt); }
 };
 
 // block -> tile.  Blocks b and b+8 share an XCD (and its 4 MiB L2), so each XCD gets a contiguous run
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
             glds16(t.w[piece - A_ITERS] + w_koff, la + A_BYTES + ((piece - A_ITERS) * NW + wave) * 1024);
     };
     auto stage = [&](const TileSrc& t, int kt, int buf) {
-        const int64_t a_koff = stage_a_offset(kt), w_koff = (int64_t)kt * 128;
+        const int64_t a_koff = stage_a_offset(kt), w_koff = walk.w_off(kt);
 #pragma unroll
         for (int i = 0; i < A_ITERS + B_ITERS; ++i) stage_piece(t, i, a_koff, w_koff, buf);
     };
@@ -948,7 +963,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         for (int i = 0; i < A_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
     };
     auto stage_W = [&](const Src& t, int kt, int slot) {  // group 1
-        const char* base = uniform_ptr(t.base + (int64_t)kt * 128);
+        const char* base = uniform_ptr(t.base + walk.w_off(kt));
         const unsigned dst = smem_base + W_RING + slot * B_BYTES + gw * 1024;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
@@ -1731,7 +1746,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(const GemmParams
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
     auto stage = [&](int kt, int slot) {
         const char* ab = uniform_ptr(a_base + stage_a_offset(kt));
-        const char* wb = uniform_ptr(w_base + (int64_t)kt * 128);
+        const char* wb = uniform_ptr(w_base + walk.w_off(kt));
         const unsigned dst = smem_base + slot * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) glds16_raw(ab, a_off[i], dst + i * (NW * 1024));
