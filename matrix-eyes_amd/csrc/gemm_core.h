@@ -1428,12 +1428,19 @@ void gemm_launch_8ph(const GemmParams& p, hipStream_t stream) {
 //
 // K order: input-channel slab outermost, taps inside (the weights are packed [Cout][tap][Cin], so a slab is the 128
 // bytes at (tap * Cin + c * 64) * 2 of a weight row).  LDS: two halo slots of 328 rows + two weight slots of 256 rows
-// (148 KiB); the halo image is [pixel hy * 18 + hx][64 channels] with chunk c of a pixel at slot c ^ ((hx >> 1) & 7), so
+// (148 KiB); the halo image is [pixel hy * 18 + hx][64 channels] with chunk c of a pixel at slot c ^ halo_swizzle(hx), so
 // the B-operand fragment of output row ty, tap (ky, kx) is the 16 consecutive rows (ty + ky) * 18 + kx + (0..15).
 // Roles: group 0 (waves 0-3) stages the weight rows of slab s+1 at the top of slab s; group 1 (waves 4-7, priority 1)
 // computes first and stages, mid-slab, two pieces per wave of the NEXT channel slab's halo during taps 0-5 (48 pieces
 // for the 41 needed), retired by its vmcnt(0) at the end of tap 8.  One barrier per slab.
 // Requires KH = KW = 3, stride 1, out_H and out_W multiples of 16, Cin a multiple of 64, N a multiple of 4.
+// Chunk swizzle of the halo image: chunk c of the pixel in halo column hx (0 .. 17) sits at slot c ^ halo_swizzle(hx).
+// The fragment reads of tap column kx touch the 16 consecutive columns kx .. kx + 15, and the usual (hx >> 1) & 7 is
+// conflict-free only for kx = 0 (28.6 % of the LDS cycles of the first build were bank conflicts,
+// profiles/r03_pmc_kernels.json).  This table -- one 3-bit value per column PAIR, found by search -- gives every
+// 16-lane group of ds_read_b128 sixteen distinct (row parity, slot) pairs for kx = 0, 1 AND 2, in both k-substeps.
+__device__ __forceinline__ int halo_swizzle(int hx) { return (int)((0xcb5888u >> (3 * (hx >> 1))) & 7u); }
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     constexpr int BN = 256, HW = 4, WN = 4;
@@ -1499,7 +1506,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
         r = r < 324 ? r : 323;                              // the 4 pad rows repeat the last pixel (never read)
         const int hy = (r * 3641) >> 16;                    // r / 18 for r < 324
         const int hx = r - hy * 18;
-        const int chunk = sslot ^ ((hx >> 1) & 7);          // the halo image's swizzle goes by the pixel's COLUMN
+        const int chunk = sslot ^ halo_swizzle(hx);         // the halo image's swizzle goes by the pixel's COLUMN
         const unsigned off = (unsigned)(((hy * p.in_Wp + hx) * p.Cin + c * 64) * 2 + chunk * 16);
         glds16_raw(uniform_ptr(t.a), off, smem_base + slot * HALO_BYTES + pc * 1024);
     };
@@ -1517,7 +1524,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int hx = kx + frow;
-        a_col[kx] = hx * 128 + ((q4 ^ ((hx >> 1) & 7)) << 4);
+        a_col[kx] = hx * 128 + ((q4 ^ halo_swizzle(hx)) << 4);
     }
 
     if (group == 1) __builtin_amdgcn_s_setprio(1);
