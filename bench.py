@@ -365,7 +365,9 @@ def main():
                 "workload": (("BASELINE.json configs[3] at one image: single 1536x1536 image, ViT linears on MX fp8 MFMA, "
                               "the rest f16, depth map + FOV head" if args.dtype == "fp8" else
                               "BASELINE.json configs[1]: single 1536x1536 image, 16-bit MFMA HIP path on "
-                              "1xMI355X, depth map + FOV head") if (B == 1 and not args.no_fov) else
+                              "1xMI355X, depth map + FOV head" +
+                              ("" if args.dtype != "f16" else " (f16 operands: the fp16 checkpoint bit for bit, 7.1e-4 relative L2 "
+                               "from the fp32 CPU path; bf16 operands measure 1.06e-2, outside north_star's 1e-3)")) if (B == 1 and not args.no_fov) else
                              f"{B} x 1536x1536 images per GPU per step, " +
                              ("f_norm given" if args.no_fov else "FOV head")),
                 "batch_per_gpu": B,
