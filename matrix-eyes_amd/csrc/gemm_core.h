@@ -536,6 +536,78 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         float amax16 = 0.f;
         auto run = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
+            if constexpr (EPI == EPI_RESID_SCALE) {
+                // The ViT updates its token stream in place (res32 == out32), and even where it does not the compiler
+                // has to assume so: written granule by granule, every residual load stays behind the store before it
+                // and the epilogue is a chain of dependent  load -> s_waitcnt vmcnt(0) -> store  round trips, 32 per
+                // wave and tile (the ISA showed exactly that; 16.6 us of a 42 us proj tile).  Here the eight residual
+                // loads of a pass are issued together and one pass ahead -- between the arithmetic of the pass before
+                // and its stores -- so a wave pays the memory latency once per tile and the stores never wait.
+                static_assert(!TILE2D, "the residual epilogue walks consecutive rows");
+                constexpr int NP = MI / MI_CH;
+                // Addresses: buffer instructions on a descriptor of this wave's TM x TN block -- ONE per-lane 32-bit byte
+                // offset for all 64 loads and stores of the tile, the row group of an access in an SGPR offset (the
+                // kernel has no VGPRs for sixteen 64-bit row pointers beside two passes of data).  Rows >= M and columns
+                // >= N are masked by the hardware range check: their offset is pushed beyond num_records (loads return 0,
+                // stores are dropped), so the bursts carry no branches.
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const int mw = m0 + wm * TM;  // first row of this wave's block
+                const int64_t wave_el = (int64_t)mw * p.ldc + n0 + wn * TN;
+                const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(uniform_ptr((const char*)(p.res32 + wave_el))), 0, 0x7fffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(uniform_ptr((const char*)(p.out32 + wave_el))), 0, 0x7fffffff, 0x00020000);
+                const unsigned row_step = (unsigned)p.ldc * 4u;  // bytes per row
+                const unsigned loff = (unsigned)r0 * row_step + gc * 32u;
+                const int rows_left = p.M - mw - r0;  // this lane's rows r0 + rt exist for rt < rows_left
+                constexpr unsigned kOut = 0x80000000u;
+                auto voff = [&](int rt, bool col_ok) { return rt < rows_left && col_ok ? loff : kOut; };
+                f32x4 res[ITERS][2];
+                auto load_res = [&](int pass) {
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int rt = pass * ROWS + it * RPI;
+                        const unsigned so = (unsigned)rt * row_step;
+                        res[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, voff(rt, n_ok), so, 0));
+                        res[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, voff(rt, hi_ok) + 16u, so, 0));
+                    }
+                };
+                load_res(0);
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+#pragma unroll
+                    for (int i = 0; i < MI_CH; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            *reinterpret_cast<f32x4*>(epi_lds + (i * 16 + frow) * RS +
+                                                      ((((j * 16 + ncol) >> 2) ^ frow) & CMASK) * 16) =
+                                acc[pass * MI_CH + i][j];
+                    f32x4 o[ITERS][2];
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int rr = it * RPI + r0;
+                        const char* src = epi_lds + rr * RS;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((2 * gc + h) ^ rr) & CMASK) * 16);
+                            // same operation order as the reference: (xs * gamma) + residual
+                            o[it][h] = f32x4{(v[0] + lc.bias[h].x) * lc.gamma[h].x + res[it][h][0],
+                                             (v[1] + lc.bias[h].y) * lc.gamma[h].y + res[it][h][1],
+                                             (v[2] + lc.bias[h].z) * lc.gamma[h].z + res[it][h][2],
+                                             (v[3] + lc.bias[h].w) * lc.gamma[h].w + res[it][h][3]};
+                        }
+                    }
+                    if (pass + 1 < NP) load_res(pass + 1);
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int rt = pass * ROWS + it * RPI;
+                        const unsigned so = (unsigned)rt * row_step;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o[it][0]), rout, voff(rt, n_ok), so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o[it][1]), rout, voff(rt, hi_ok) + 16u, so, 0);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int pass = 0; pass < MI / MI_CH; ++pass) {
 #pragma unroll
