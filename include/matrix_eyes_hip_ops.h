@@ -63,6 +63,14 @@ int32_t me_op_layernorm_fp8(me_ctx* ctx, const float* x32, const float* weight, 
 int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
                          const uint8_t* W8, const uint8_t* w_scale, const float* bias, void* out16, uint8_t* out8,
                          uint8_t* out8_scale, const float* gamma, float* x32);
+/* me_op_linear / me_op_linear_residual over up to three row segments with their own weights, as the encoder's merged
+   ViT launches run them (pipeline.hip MergedVit): rows [0, seg1) use W16[0] / bias[0] (/ gamma[0]), [seg1, seg2) the [1]
+   set, [seg2, M) the [2] set; seg2 == 0: two segments, seg1 == 0: one.  x32 given: the residual form (gamma taken);
+   otherwise out16 = act(A . W^T + bias).  Segment boundaries must be multiples of the tile height of tile_cfg, except
+   for the 352-row tile (tile_cfg 10), which lays its row tiles out per segment. */
+int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1, int32_t seg2,
+                              const void* const W16[3], const float* const bias[3], const float* const gamma[3],
+                              void* out16, float* x32, int32_t act, int32_t tile_cfg);
 /* me_op_linear_fp8 over up to three row segments with their own weights, as the encoder's merged ViT launches run
    it (pipeline.hip MergedVit): rows [0, seg1) use W8[0] / w_scale[0] / bias[0] (/ gamma[0]), [seg1, seg2) the [1]
    set, [seg2, M) the [2] set; seg1, seg2 multiples of 256, seg2 == 0: two segments, seg1 == 0: one. */

@@ -916,6 +916,26 @@ int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, 
     ME_API_END(ctx)
 }
 
+int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1, int32_t seg2,
+                              const void* const W16[3], const float* const bias[3], const float* const gamma[3],
+                              void* out16, float* x32, int32_t act, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(A16 && W16 && bias && (out16 || x32), ME_ERR_BAD_ARG, "me_op_linear_segments: null pointer");
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16[0], p.bias = bias[0], p.ldc = N;
+    p.seg1 = seg1, p.seg2 = seg2, p.W_s1 = W16[1], p.bias_s1 = bias[1], p.W_s2 = W16[2], p.bias_s2 = bias[2];
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    if (x32) {
+        ME_CHECK(gamma, ME_ERR_BAD_ARG, "me_op_linear_segments: the residual form takes gamma");
+        p.gamma = gamma[0], p.gamma_s1 = gamma[1], p.gamma_s2 = gamma[2], p.res32 = x32, p.out32 = x32;
+        gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, ctx->stream, tile_cfg);
+    } else {
+        p.out16 = out16, p.act = act;
+        gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, ctx->stream, tile_cfg);
+    }
+    ME_API_END(ctx)
+}
+
 int32_t me_op_format_f64(me_ctx* ctx, const double* values, int64_t count, char* text, int32_t stride, int32_t* lengths) {
     ME_API_BEGIN(ctx)
     ME_CHECK(values && text && lengths && count >= 0, ME_ERR_BAD_ARG, "me_op_format_f64: bad argument");

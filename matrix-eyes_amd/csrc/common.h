@@ -238,6 +238,15 @@ struct GemmParams {
 };
 constexpr int kGemmQueueWords = 9 * 32;
 
+// row tiles of a launch tiled per row segment (gemm_core.h seg_tile_rows; the 352-row tile)
+template <int BM>
+__host__ __device__ __forceinline__ int seg_row_tiles(int M, int seg1, int seg2) {
+    if (seg1 == 0) return (M + BM - 1) / BM;
+    const int e1 = seg2 ? seg2 : M;
+    return (seg1 + BM - 1) / BM + (e1 - seg1 + BM - 1) / BM + (seg2 ? (M - seg2 + BM - 1) / BM : 0);
+}
+
+
 // dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).
 void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg = -1);

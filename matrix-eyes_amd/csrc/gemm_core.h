@@ -218,15 +218,35 @@ struct SlabWalk {
     __device__ __forceinline__ int64_t next(const GemmParams& p, int kt) const { return a_off(p, kt); }
 };
 
+// Row tiles of a launch whose tile height does not divide the row-segment boundaries (the 352-row tile): every segment is
+// tiled from its own first row, a tile never straddles a boundary, and the rows a segment's last tile has beyond the
+// segment's end are neither computed into nor stored (row limit of the tile = the end of its segment).  For tile
+// heights that divide seg1 and seg2 this is the plain m0 = row_tile * BM.
+template <int BM>
+__device__ __forceinline__ void seg_tile_rows(const GemmParams& p, int rt, int& m0, int& m_lim) {
+    if (p.seg1 == 0) {
+        m0 = rt * BM, m_lim = p.M;
+        return;
+    }
+    const int e1 = p.seg2 ? p.seg2 : p.M;
+    const int t0 = (p.seg1 + BM - 1) / BM, t1 = (e1 - p.seg1 + BM - 1) / BM;
+    if (rt < t0)
+        m0 = rt * BM, m_lim = p.seg1;
+    else if (rt < t0 + t1)
+        m0 = p.seg1 + (rt - t0) * BM, m_lim = e1;
+    else
+        m0 = p.seg2 + (rt - t0 - t1) * BM, m_lim = p.M;
+}
+
 // block -> tile.  Blocks b and b+8 share an XCD (and its 4 MiB L2), so each XCD gets a contiguous run
 // of the tile order; that order walks "super-rows" of 8 tile rows column by column, so the ~32 tiles
 // an XCD has in flight form an 8 x 4 patch: every A k-slab is shared by 4 of them and every W k-slab
 // by 8 (with the plain n-fastest order the whole W matrix streams through L2 once per tile row:
 // 44 % L2 misses on the fc1 shape, profiles/r01_pmc_gemm.md).
-template <int BM, int BN>
-__device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0) {
+template <int BM, int BN, bool SEG = false>
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0, int* m_lim = nullptr) {
     constexpr int GM = 8;
-    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nbm = SEG ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);  // bijective
     const int per_sr = GM * nbn;
@@ -235,7 +255,14 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nw
     const int h = min(GM, nbm - sr * GM);  // rows of this super-row
     const int n = rem / h;
     const int rr = rem - n * h;
-    m0 = (sr * GM + rr) * BM;
+    if constexpr (SEG) {
+        int lim;
+        seg_tile_rows<BM>(p, sr * GM + rr, m0, lim);
+        if (m_lim) *m_lim = lim;
+    } else {
+        m0 = (sr * GM + rr) * BM;
+        if (m_lim) *m_lim = p.M;
+    }
     n0 = n * BN;
 }
 
@@ -441,7 +468,9 @@ template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool P
           typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
                                               int wm, int wn, int lane, char* epi_lds,
-                                              Hook after_loads = Hook()) {
+                                              Hook after_loads = Hook(), int m_lim = -1) {
+    // rows >= Mrows are not stored: p.M, or the end of the tile's row segment (seg_tile_rows)
+    const int Mrows = m_lim < 0 ? p.M : m_lim;
     const int frow = lane & 15;
     const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
     if constexpr (EPI == EPI_HEAD_FINAL) {
@@ -467,7 +496,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             const int m = m0 + wm * TM + i * 16 + frow;
-            if (lane < 16 && m < p.M) {
+            if (lane < 16 && m < Mrows) {
                 float v = fmaxf(s + p.b2[0], 0.f);
                 if (p.f_norm) v = v / p.f_norm[m / p.pixels_per_image];
                 v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
@@ -527,7 +556,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         const bool pix = !TILE2D && (EPI == EPI_CONVT || (EPI == EPI_STORE && p.out16_border));
         if (pix) {  // one pair of divisions per lane; afterwards the pixel walks with the row
             const int ppi = p.out_H * p.out_W;
-            const int mm = row.m < p.M ? row.m : p.M - 1;
+            const int mm = row.m < Mrows ? row.m : Mrows - 1;
             row.b = mm / ppi;
             const int rem = mm - row.b * ppi;
             row.y = rem / p.out_W;
@@ -559,7 +588,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     const_cast<char*>(uniform_ptr((const char*)(p.out32 + wave_el))), 0, 0x7fffffff, 0x00020000);
                 const unsigned row_step = (unsigned)p.ldc * 4u;  // bytes per row
                 const unsigned loff = (unsigned)r0 * row_step + gc * 32u;
-                const int rows_left = p.M - mw - r0;  // this lane's rows r0 + rt exist for rt < rows_left
+                const int rows_left = Mrows - mw - r0;  // this lane's rows r0 + rt exist for rt < rows_left
                 constexpr unsigned kOut = 0x80000000u;
                 auto voff = [&](int rt, bool col_ok) { return rt < rows_left && col_ok ? loff : kOut; };
                 f32x4 res[ITERS][2];
@@ -651,7 +680,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
-                    if (row.m < p.M && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16);
+                    if (row.m < Mrows && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16);
                     if constexpr (TILE2D) {
                         t2_row += RPI;
                         row.y = t2_y0 + (t2_row >> 4), row.x = t2_x0 + (t2_row & 15);
@@ -952,8 +981,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
 // (160 KiB for the 256x256 tile: all of a CU's LDS).  One barrier per slab as before; group 1 closes a
 // slab with a counted vmcnt (its newest DMA group may stay in flight), group 0 with vmcnt(0).
 // Requires K >= 128.
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    static_assert(WSLOTS == 3 || WSLOTS == 2, "weight ring of three slots (two slabs ahead) or two (one ahead)");
     static_assert(WM * WN == 8, "two groups of four waves");
     static_assert(BM / WM >= BN / WN, "the first k-substep's MI groups prefetch the NI weight fragments");
     constexpr int HW = 4;  // waves per group
@@ -976,20 +1006,43 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2, gw = wave & 3;  // waves w and w + 4 share a SIMD
     const int wm = wave / WN, wn = wave % WN;
-    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    // TALL (the 352-row tile): row tiles laid out per row segment (seg_tile_rows), DMA source offsets kept as
+    // {first, step, clamp} instead of one register per piece (22 VGPRs of the two tiles in flight become 4)
+    constexpr bool TALL = BM > 256;
+    static_assert(!TALL || AMODE == A_PLAIN, "the tall tile's affine source offsets need row-major activations");
+    const int ntiles = (TALL ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
 
     const int srow = lane >> 3, sslot = lane & 7;
     struct Src {
-        int m0, n0;
+        int m0, n0, m_lim;
         // this wave's DMA sources, activation rows (group 0) or weight rows (group 1): a uniform base (the
         // tile's first row) and per-lane 32-bit byte offsets from it -- the kernel has no VGPR to spare
         // for 64-bit pointers
         const char* base;
-        unsigned s[IT];
+        unsigned s[TALL ? 2 : IT];  // TALL: {offset of the first piece, largest offset that stays inside the operand}
     };
     auto pixel_of = [&](int gm) -> int64_t { return conv_pixel(p, gm); };
     auto setup = [&](Src& t, int vb) {
-        tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
+        tile_origin<BM, BN, TALL>(p, vb, ntiles, t.m0, t.n0, &t.m_lim);
+        if constexpr (TALL) {
+            // piece i of a lane: row (i * HW + gw) * 8 + srow of the tile, always the same 16-byte chunk position
+            // (the swizzle repeats every 16 rows) -- offsets are affine in i; rows beyond the operand's last row
+            // read that last row instead (their products are never stored)
+            const int row = gw * 8 + srow;
+            const unsigned chunk16 = (unsigned)(sslot ^ ((row >> 1) & 7)) * 16u;
+            if (group == 0) {
+                t.base = (const char*)p.A + (int64_t)t.m0 * p.lda * 2;
+                const int last = p.M - 1 - t.m0;  // >= 0
+                t.s[0] = (unsigned)row * (unsigned)(p.lda * 2) + chunk16;
+                t.s[1] = last >= BM ? 0xffffffffu : (unsigned)last * (unsigned)(p.lda * 2) + chunk16;
+            } else {
+                t.base = segment_weights(p, t.m0) + (int64_t)t.n0 * p.K * 2;
+                const int last = p.N - 1 - t.n0;
+                t.s[0] = (unsigned)row * (unsigned)(p.K * 2) + chunk16;
+                t.s[1] = last >= BN ? 0xffffffffu : (unsigned)last * (unsigned)(p.K * 2) + chunk16;
+            }
+            return;
+        }
         if (group == 0) {
             int64_t base_el;  // element offset of the tile's first row (uniform)
             if constexpr (AMODE == A_PLAIN)
@@ -1031,12 +1084,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     auto stage_T = [&](const Src& t, int kt, int slot) {  // group 0
         const char* base = uniform_ptr(t.base + stage_a_offset(kt));
         const unsigned dst = smem_base + slot * A_BYTES + gw * 1024;
+        if constexpr (TALL) {
+            const unsigned step = (unsigned)(HW * 8) * (unsigned)(p.lda * 2);
+            unsigned first = t.s[0];
+            asm volatile("" : "+v"(first));  // recomputed per slab (two VALU per piece): hoisted, the A_IT offsets spill
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) glds16_raw(base, min(first + i * step, t.s[1]), dst + i * (HW * 1024));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
     };
     auto stage_W = [&](const Src& t, int kt, int slot) {  // group 1
         const char* base = uniform_ptr(t.base + walk.w_off(kt));
         const unsigned dst = smem_base + W_RING + slot * B_BYTES + gw * 1024;
+        if constexpr (TALL) {
+            const unsigned step = (unsigned)(HW * 8) * (unsigned)(p.K * 2);
+            unsigned first = t.s[0];
+            asm volatile("" : "+v"(first));
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) glds16_raw(base, min(first + i * step, t.s[1]), dst + i * (HW * 1024));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) glds16_raw(base, t.s[i], dst + i * (HW * 1024));
     };
@@ -1057,7 +1126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     int vb = blockIdx.x;
     Src cur, nxt;
     setup(cur, vb);
-    const bool dyn = p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
+    const bool dyn = WSLOTS == 3 && p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
     TileQueue tq;
     tq.init(p.queue, ntiles);
     int next_vb = vb + (int)gridDim.x;
@@ -1069,8 +1138,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         stage_W(cur, 0, 0);
-        stage_W(cur, 1, 1);
-        if constexpr (B_IT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (WSLOTS == 3) stage_W(cur, 1, 1);
+        if constexpr (WSLOTS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (B_IT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (B_IT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1153,13 +1223,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             ME_PHASE(1);
             bool newer = false;  // group 1: a DMA group younger than the one the next slab needs
             if (group == 1) {
-                const int w2 = ws == 0 ? 2 : ws - 1;  // (ws + 2) % 3
-                if (kt + 2 < nk) {
-                    stage_W(cur, kt + 2, w2);
-                    newer = true;
-                } else if (has_next) {
-                    stage_W(nxt, kt + 2 - nk, w2);
-                    newer = true;
+                if constexpr (WSLOTS == 3) {
+                    const int w2 = ws == 0 ? 2 : ws - 1;  // (ws + 2) % 3
+                    if (kt + 2 < nk) {
+                        stage_W(cur, kt + 2, w2);
+                        newer = true;
+                    } else if (has_next) {
+                        stage_W(nxt, kt + 2 - nk, w2);
+                        newer = true;
+                    }
+                } else {  // two slots: the next slab's weights, into the slot the slab before this one has left
+                    if (kt + 1 < nk)
+                        stage_W(cur, kt + 1, ws ^ 1);
+                    else if (has_next)
+                        stage_W(nxt, 0, ws ^ 1);
                 }
             }
             ME_PHASE(2);
@@ -1186,18 +1263,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
             asm volatile("" ::: "memory");
             ME_PHASE(5);
             ts ^= 1;
-            ws = ws == 2 ? 0 : ws + 1;
+            ws = WSLOTS == 2 ? (ws ^ 1) : (ws == 2 ? 0 : ws + 1);
         }
         ME_STAMP();
         // ts / ws now name the next tile's first slab; the slots consumed last are the scratch
         char* scratch0 = smem + (ts ^ 1) * A_BYTES;  // group 0's region; its first word doubles as hand-off
         int drawn = -1;                              // lane 0 of wave 0: the tile after next
         {
-            const int wprev = ws == 0 ? 2 : ws - 1;
+            const int wprev = WSLOTS == 2 ? (ws ^ 1) : (ws == 0 ? 2 : ws - 1);
             char* scr = (group == 0 ? scratch0 : smem + W_RING + wprev * B_BYTES) + gw * SCR;
             gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, scr, [&]() {
                 if (dyn && has_next && tid == 0) drawn = tq.draw();
-            });
+            }, TALL ? cur.m_lim : -1);
         }
         ME_STAMP();
         if (!has_next) {
@@ -1228,11 +1305,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #undef ME_STAMP
 #undef ME_PHASE
 
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3>
 void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = (2 * BM + 3 * BN) * 128;
+    constexpr int smem = (2 * BM + WSLOTS * BN) * 128;
+    static_assert(smem <= 160 * 1024, "the tile's rings exceed a CU's LDS");
     ME_CHECK(p.K >= 128, ME_ERR_BAD_SHAPE, "gemm: the two-group kernel needs K >= 128 (K = %d)", p.K);
-    auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
+    auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI, WSLOTS>;
     static PerDeviceOnce once;
     const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1243,7 +1321,7 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
         r -= r % 8;
         return r < 8 ? 8 : r;
     });
-    const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    const int64_t ntiles = (BM > 256 ? (int64_t)seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : cdiv(p.M, BM)) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
     int64_t grid = ntiles < resident ? ntiles : resident;
@@ -1936,6 +2014,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
                     conv_halo_launch<T, EPI>(p, stream);                                  \
                 else                                                                      \
                     fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
+                break;                                                                    \
+            case 10: /* 352-row two-group tile, two weight slots: one exact round where 256-row tiles leave a tail */ \
+                if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \
+                    gemm_launch_pp<T, 352, 256, 2, 4, AMODE, EPI, 2>(p, stream);          \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the 352-row tile takes plain linears with store / residual epilogues only"); \
                 break;                                                                    \
             case 6:                                                                       \
                 if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \

@@ -383,6 +383,25 @@ struct MergedVit {
         return true;
     }
 
+    // The 352-row tile (tile config 10).  256 CUs x one tile each cover 64 x 352 = 22528 rows of an N = 1024 launch: at
+    // one image proj / fc2 are ONE exact round (3 + 3 + 58 row tiles x 4 = 256 tiles) instead of a round of 256x256
+    // tiles and a second launch of short tiles that the CU cannot stage fast enough (1.375 tile-times against 1 + 0.69),
+    // and fc1 is four rounds instead of five and a tail.  Chosen when its rounds x 352 undercut what the 256-row path
+    // costs (whole rounds x 256, + 0.69 x 256 for a short tail or a whole round where no tail applies); qkv's 1020
+    // tiles of 256x256 are 3.98 rounds and stay.  ME_GEMM_TALL=0 turns it off.
+    bool tall_tile_wins(const GemmParams& p) const {
+        static const bool enabled = !(getenv("ME_GEMM_TALL") && atoi(getenv("ME_GEMM_TALL")) == 0);
+        if (!enabled || p.N % 256 || p.K < 128 || ctx->C() < 256) return false;
+        const int64_t nbn = p.N / 256;
+        const int64_t tiles352 = (int64_t)seg_row_tiles<352>(p.M, p.seg1, p.seg2) * nbn;
+        const int64_t tiles256 = cdiv(p.M, 256) * nbn;
+        const double cost352 = (double)cdiv(tiles352, 256) * 352.0;
+        const int64_t whole = tiles256 / 256, rem = tiles256 % 256;
+        const bool short_tail = whole >= 1 && rem != 0 && 2 * rem <= 256 && 256 % nbn == 0;
+        const double cost256 = ((double)whole + (rem == 0 ? 0.0 : (short_tail ? 0.69 : 1.0))) * 256.0;
+        return cost352 < cost256;
+    }
+
     // one GEMM over all segments (three weight sets): 16-bit output (qkv, fc1) ...
     void gemm_all(const void* A, int K, const void* w0, const void* w1, const void* w2, const float* b0,
                   const float* b1, const float* b2, int N, void* out16, int act) {
@@ -393,6 +412,10 @@ struct MergedVit {
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = b1, p.W_s2 = w2, p.bias_s2 = b2;
         // fc1 at one image: five whole rounds + 224 short tiles instead of a sixth round a third full (qkv's 1020 tiles
         // are 3.98 rounds and N = 3072 does not divide the round: launch_with_short_tail declines)
+        if (tall_tile_wins(p)) {
+            gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s, 10);
+            return;
+        }
         if (ctx->C() >= 256 && launch_with_short_tail(p, EPI_STORE, w1, b1, nullptr, w2, b2, nullptr)) return;
         gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
     }
@@ -415,6 +438,10 @@ struct MergedVit {
         static const bool use_pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const bool pp = C >= 256 && K >= 128;
         const bool pp192 = pp && K <= 1024 && use_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
+        if (pp && !pp192 && tall_tile_wins(p)) {
+            gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, 10);
+            return;
+        }
         if (pp && !pp192 && launch_with_short_tail(p, EPI_RESID_SCALE, w1, bb1, g1, w2, bb2, g2)) return;
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, pp192 ? 5 : (pp ? 0 : -1));
     }

@@ -176,6 +176,76 @@ def test_linear_residual(dtype, cfg):
     assert max_abs_rel(x, ref) < 2e-5
 
 
+def _segmented_linear(ctx, dtype, M, N, K, seg1, seg2, cfg, resid, seed, act=0):
+    """me_op_linear_segments on seeded operands; returns (result, fp64 reference)"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(seed)
+    a = dev16(torch.randn(M, K, generator=g), dtype)
+    ws = [dev16(torch.randn(N, K, generator=g) / math.sqrt(K), dtype) for _ in range(3)]
+    bs = [torch.randn(N, generator=g).cuda() for _ in range(3)]
+    gs = [(0.05 + 0.15 * torch.rand(N, generator=g)).cuda() for _ in range(3)]
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    bounds = [0, seg1 if seg1 else M, (seg2 if seg2 else M) if seg1 else M, M]
+    x0 = torch.randn(M, N, generator=g).cuda()
+    ref = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi <= lo:
+            continue
+        y = a[lo:hi].double() @ ws[i].double().T + bs[i].double()
+        ref[lo:hi] = x0[lo:hi].double() + gs[i].double() * y if resid else (F.gelu(y) if act == 1 else y)
+    if resid:
+        x = x0.clone()
+        torch.cuda.synchronize()      # torch's fills run on torch's stream, the op on the context's
+        _check(ctx, ctx.lib.me_op_linear_segments(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), None,
+                                                  ptr(x), 0, cfg))
+        ctx.synchronize()
+        return x, ref
+    out16 = torch.full((M, N), float("nan"), dtype=TORCH16[dtype], device="cuda")
+    torch.cuda.synchronize()
+    _check(ctx, ctx.lib.me_op_linear_segments(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), ptr(out16),
+                                              None, act, cfg))
+    ctx.synchronize()
+    return out16, ref
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("resid", [False, True])
+@pytest.mark.parametrize("shape", [
+    # (M, N, K, seg1, seg2): one segment with a ragged last tile; the merged ViT row space of one image in small (three
+    # segments on 256-row boundaries: 3 + 3 + ... row tiles of 352); boundaries that no other tile height allows
+    (1000, 256, 128, 0, 0), (577, 512, 256, 0, 0), (5000, 260, 192, 0, 0), (352, 256, 128, 0, 0), (353, 256, 128, 0, 0),
+    (3000, 512, 256, 768, 1536), (2500, 256, 128, 600, 1300), (1500, 256, 128, 700, 0), (90000, 256, 128, 768, 1536),
+])
+def test_tall_tile_352(dtype, resid, shape):
+    """Tile config 10 (352x256, two weight slots, row tiles laid out per segment): against fp64, and -- where the
+    256-row tile takes the same problem -- bit for bit against tile config 0 (same K order per output element)."""
+    M, N, K, seg1, seg2 = shape
+    ctx = ctx_for("tiny", dtype)
+    got, ref = _segmented_linear(ctx, dtype, M, N, K, seg1, seg2, 10, resid, seed=M + N + K, act=0 if resid else 1)
+    if resid:
+        assert max_abs_rel(got, ref) < 2e-5
+    else:
+        assert not bool(torch.isnan(got.float()).any())          # every row of every segment was stored
+        assert max_abs_rel(got.float(), ref) < 4 * OUT_EPS[dtype] * 4
+    if seg1 % 256 == 0 and seg2 % 256 == 0 and N % 4 == 0:
+        same, _ = _segmented_linear(ctx, dtype, M, N, K, seg1, seg2, 0, resid, seed=M + N + K, act=0 if resid else 1)
+        assert torch.equal(got, same)
+
+
+def test_tall_tile_352_at_the_step_shapes():
+    """proj / fc2 / fc1 of one 1536x1536 image (M = 21760 in segments of 768 / 768 / 20224 rows): one exact round of
+    256 tall tiles (proj, fc2), four rounds (fc1); bit-identical to the 256-row tile."""
+    ctx = ctx_for("tiny", "f16")
+    for (N, K, resid) in ((1024, 1024, True), (1024, 4096, True), (4096, 1024, False)):
+        got, ref = _segmented_linear(ctx, "f16", 21760, N, K, 768, 1536, 10, resid, seed=N + K, act=0 if resid else 1)
+        same, _ = _segmented_linear(ctx, "f16", 21760, N, K, 768, 1536, 0, resid, seed=N + K, act=0 if resid else 1)
+        assert torch.equal(got, same)
+        if resid:
+            assert max_abs_rel(got, ref) < 1e-4        # f32 accumulation over K = 4096
+        del got, ref, same
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("tokens,windows,heads", [(577, 3, 2), (65, 5, 2), (577, 1, 16), (130, 2, 1)])
 def test_attention(dtype, tokens, windows, heads):
