@@ -561,22 +561,24 @@ np.save(sys.argv[2], d)
 """
 
 
-def test_short_tail_launches_change_no_bit(tmp_path):
-    """pipeline.hip launch_with_short_tail: at one image the last, third-full round of fc1 / proj / fc2 runs as a second
-    launch of 96x256 tiles over the remaining rows.  Same K order per output element, so the full-size depth is bit
-    for bit that of the single-launch form (ME_GEMM_TAIL96=0)."""
+def test_tile_choices_change_no_bit(tmp_path):
+    """The three ways proj / fc2 / fc1 of one image can run -- ONE round of 352-row tiles laid out per row segment
+    (pipeline.hip tall_tile_wins, the default), whole rounds of 256x256 + a second launch of 96x256 tiles over the
+    remaining rows (launch_with_short_tail; ME_GEMM_TALL=0), single 256x256 launches (and ME_GEMM_TAIL96=0) -- keep
+    the same K order per output element: the full-size depth is bit for bit the same."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, extra in (("split", {}), ("single", {"ME_GEMM_TAIL96": "0"})):
+    for name, extra in (("tall", {}), ("split", {"ME_GEMM_TALL": "0"}),
+                        ("single", {"ME_GEMM_TALL": "0", "ME_GEMM_TAIL96": "0"})):
         path = str(tmp_path / (name + ".npy"))
         r = subprocess.run([sys.executable, "-c", _TAIL_CHILD, root, path], env=dict(os.environ, **extra),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_reconstruction_end_to_end_with_pt_checkpoint(tmp_path):

@@ -28,11 +28,11 @@ for (N, K, name, cfg) in [(3072, 1024, "qkv", PP), (1024, 4096, "fc2", 3), (4096
     lib.me_debug_set_stamps(None)
     raw = stamps.cpu().numpy()
     s = raw.reshape(-1, 16).astype(np.float64)
-    nwg = int(np.sum(s[:256, 0] > 0)) if cfg in (0, 5, 7) else int(np.sum(s[:512, 0] > 0))
-    nw = 8 if cfg in (0, 5, 7) else 4
-    npz = 8 if cfg in (0, 5, 7) else 4
+    nwg = int(np.sum(s[:256, 0] > 0)) if cfg in (0, 5, 7, 10) else int(np.sum(s[:512, 0] > 0))
+    nw = 8 if cfg in (0, 5, 7, 10) else 4
+    npz = 8 if cfg in (0, 5, 7, 10) else 4
     ph = raw[nwg * 16: nwg * 16 + nwg * nw * npz].reshape(nwg, nw, npz).astype(np.float64)
-    names = ["dma top", "k-substep 0", "dma mid", "k-substep 1", "vmcnt", "barrier"] if cfg in (0, 5, 7) else ["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]
+    names = ["dma top", "k-substep 0", "dma mid", "k-substep 1", "vmcnt", "barrier"] if cfg in (0, 5, 7, 10) else ["dma issue", "reads+mfma", "vmcnt(0)", "barrier"]
     s = s[:nwg]
     t0 = s[:, 0].min()
     us = (s - t0) / 100.0   # 100 MHz
