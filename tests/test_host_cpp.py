@@ -216,6 +216,48 @@ def test_lanczos3_against_pillow(tmp_path, size):
     assert got.shape == want.shape and np.abs(got - want).max() <= 1     # one code of rounding at most
 
 
+@pytest.mark.parametrize("case", [((300, 200), (150, 100)), ((300, 200), (512, 384)), ((301, 199), (97, 333)),
+                                  ((64, 48), (1536, 1536)), ((40, 30), (1, 1)), ((1, 7), (5, 3)), ((257, 129), (256, 128)),
+                                  ((100, 100), (100, 100))])
+def test_lanczos3_is_the_image_crates_sampler(tmp_path, case):
+    """reconstruction.rs:107-113 / output.rs:133-137: resize_exact(.., Lanczos3) is the `image` crate's sampler (0.25.10,
+    imageops/sample.rs: rows first into an f32 intermediate, then columns; weights in f32; round half away from zero).
+    The C++ host layer against the C restatement of that algorithm in oracle/image_oracle.c: the same bytes."""
+    import ctypes as C
+    from PIL import Image
+    from oracle import output_oracle
+    output_oracle.build()
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libimage_oracle.so"))
+    (w, h), (nw, nh) = case
+    rng = np.random.default_rng(w * 7 + nh)
+    img = _photo(w, h, w + h) if w > 8 and h > 8 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img[rng.integers(0, h, 20), rng.integers(0, w, 20)] = rng.integers(0, 2, (20, 1), dtype=np.uint8) * 255   # hard edges: overshoot clamps
+    src, dst = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    Image.fromarray(img).save(src)
+    r = subprocess.run([SELFTEST, "resize", src, str(nw), str(nh), dst], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.asarray(Image.open(dst))
+    want = np.empty((nh, nw, 3), np.uint8)
+    a = np.ascontiguousarray(img)
+    assert lib.oracle_resize_lanczos3_rgb8(C.c_void_p(a.ctypes.data), C.c_int64(w), C.c_int64(h), C.c_void_p(want.ctypes.data),
+                                           C.c_int64(nw), C.c_int64(nh)) == 0
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_sixteen_bit_samples_round_like_the_image_crate():
+    """into_rgb8 of a 16-bit picture: (v + 128) / 257 per sample (image 0.25 color.rs); the oracle's one-liner against
+    the closed form over all 65536 values, and the PNG decoder applies it in test_png_every_depth_colour_type_and_adam7"""
+    import ctypes as C
+    from oracle import output_oracle
+    output_oracle.build()
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libimage_oracle.so"))
+    lib.oracle_u16_to_u8.restype = C.c_uint8
+    v = np.arange(65536)
+    want = np.rint(v / 257.0 - 1e-9).astype(int)                # nearest of v * 255 / 65535, ties cannot occur
+    got = np.array([lib.oracle_u16_to_u8(C.c_uint16(int(x))) for x in v[::17]])
+    assert np.array_equal(got, ((v[::17] + 128) // 257)) and np.abs(got - want[::17]).max() == 0
+
+
 def _photo(w, h, seed):
     """a smooth, noisy, colourful picture: what JPEG is made for"""
     rng = np.random.default_rng(seed)
