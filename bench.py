@@ -253,6 +253,11 @@ def main():
         out_dir = tempfile.mkdtemp(prefix=f"me_chain_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         noise = torch.from_numpy(np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)).cuda()
         stereo = torch.empty(B, S, S, 3, dtype=torch.uint8, device="cuda")
+        # me_ctx_set_write_behind: image i's file is written by a host thread while the GPU works on image i + 1; every
+        # file is complete (me_output_flush) before the timed region ends.  ME_CHAIN_SYNC_WRITES=1: the reference's form.
+        write_behind = os.environ.get("ME_CHAIN_SYNC_WRITES") is None
+        ctx.set_write_behind(max(2, B) if write_behind else 0)
+    chain_step = [0]
 
     def step():
         if not args.chain:
@@ -267,8 +272,10 @@ def main():
             maps[b].stereogram(1.0 / 16.0, noise, out=stereo[b])
         ctx.synchronize()
         t2 = time.perf_counter()
+        chain_step[0] += 1
         for b in range(B):
-            path = os.path.join(out_dir, f"mesh{b}.obj")
+            # two names per image slot: a file still being written behind the caller is never the next call's target
+            path = os.path.join(out_dir, f"mesh{b}_{chain_step[0] & 1}.obj")
             maps[b].output_mesh(path, "photo.jpg", m.VertexMode.Texture)
             legs = ctx.last_mesh_timing()
             chain_ms["obj_bytes"] = legs["bytes"]
@@ -291,10 +298,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.chain:
+        ctx.output_flush()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if args.chain:
+        ctx.output_flush()          # every OBJ file of the timed steps is on the file system
     fence()
     elapsed = time.perf_counter() - t0
     my_step_ms = elapsed / args.steps * 1e3
@@ -423,8 +434,12 @@ def main():
                                 "d2h_of_the_text": round(chain_report["obj_d2h"], 3),
                                 "file_write_tmpfs": round(chain_report["obj_file"], 3)},
                             "obj_bytes": chain_report["obj_bytes"],
+                            "write_behind": bool(write_behind),
                             "note": "the file write is the host kernel's page-cache copy (about 2.8 GB/s on tmpfs whatever the "
-                                    "thread count); everything before it runs on the GPU"}
+                                    "thread count); everything before it runs on the GPU.  With write_behind "
+                                    "(me_ctx_set_write_behind) a host thread writes image i's file while the GPU works on "
+                                    "image i + 1; file_write_tmpfs is then what the CALLER waited (hand-over, or an earlier "
+                                    "file still being written), and every file is flushed inside the timed region"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, args.cpu_windows)
         print(json.dumps(out), flush=True)

@@ -294,6 +294,16 @@ int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t h
                        const char* destination_path, const char* source_path, int32_t vertex_mode,
                        const uint8_t* vertex_colors);
 
+/* Write-behind for me_output_mesh(".obj") (BASELINE configs[4]: a batch of images, each ending in a file of 70 - 450 MB).
+   files_in_flight >= 2: the call returns once the text sits in pinned host memory; a host thread writes the file (and
+   the .mtl) while the caller goes on to the next image.  That many pinned buffers are used in turn, so that many files
+   can be in flight; the next call waits for the oldest (1 is taken as 2).  A failed write is reported (ME_ERR_IO,
+   me_last_error) by the call that next waits for it: a later me_output_mesh, me_ctx_set_write_behind, or
+   me_output_flush, which waits for every pending file.  me_ctx_destroy flushes.  0 (the default): the reference's
+   form, output_mesh returns with the file written. */
+int32_t me_ctx_set_write_behind(me_ctx* ctx, int32_t files_in_flight);
+int32_t me_output_flush(me_ctx* ctx);
+
 /* The OBJ text of me_output_mesh without the file: the mesh is indexed and every "vt" / "v" / "f" line formatted on
    the GPU (output.rs:484-630 ObjWriter; numbers as Rust's `{}` prints an f64), the lines packed in the reference's
    order behind the "mtllib <stem>.mtl" / "usemtl Textured" header of texture mode.  *text_dev: DEVICE address of the

@@ -108,5 +108,7 @@ extern "C" {
     pub fn me_mesh_vertices(ctx: *mut MeCtx, depth: *const f32, width: i32, height: i32, vertex_index: *const i32, nvertices: i64, original_width: u32, original_height: u32, uv: *mut f32, xyz: *mut f32) -> i32;
     pub fn me_mesh_obj_text(ctx: *mut MeCtx, depth: *const f32, width: i32, height: i32, original_width: u32, original_height: u32, stem: *const c_char, vertex_mode: i32, vertex_colors: *const u8, text_dev: *mut *const u8, nbytes: *mut i64) -> i32;
     pub fn me_last_mesh_timing(ctx: *const MeCtx, ms_out: *mut f64, text_bytes: *mut i64) -> i32;
+    pub fn me_ctx_set_write_behind(ctx: *mut MeCtx, files_in_flight: i32) -> i32;
+    pub fn me_output_flush(ctx: *mut MeCtx) -> i32;
     pub fn me_output_mesh(ctx: *mut MeCtx, depth: *const f32, width: i32, height: i32, original_width: u32, original_height: u32, destination_path: *const c_char, source_path: *const c_char, vertex_mode: i32, vertex_colors: *const u8) -> i32;
 }

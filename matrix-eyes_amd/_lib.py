@@ -80,6 +80,8 @@ SIGNATURES = {
     "me_output_mesh": (_i32, [_vp, _vp, _i32, _i32, _u32, _u32, C.c_char_p, C.c_char_p, _i32, _vp]),
     "me_mesh_obj_text": (_i32, [_vp, _vp, _i32, _i32, _u32, _u32, C.c_char_p, _i32, _vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "me_last_mesh_timing": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "me_ctx_set_write_behind": (_i32, [_vp, _i32]),
+    "me_output_flush": (_i32, [_vp]),
     # matrix_eyes_hip_ops.h
     "me_op_linear": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "me_op_linear_residual": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),

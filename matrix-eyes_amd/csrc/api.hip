@@ -189,7 +189,9 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->arena8) (void)hipFree(ctx->arena8);
     if (ctx->status_dev) (void)hipFree(ctx->status_dev);
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)me_output_flush(ctx);  // pending write-behind files are completed before their buffers go
+    for (me_ctx::WriteSlot& w : ctx->write_slots)
+        if (w.pinned) (void)hipHostFree(w.pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

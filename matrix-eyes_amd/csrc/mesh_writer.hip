@@ -255,15 +255,18 @@ void write_file_parallel(const std::string& path, const char* data, size_t bytes
     ME_CHECK(r == 0, ME_ERR_IO, "close failed: %s", strerror(errno));
 }
 
-// pinned staging buffer of the context (the D2H copy of a few hundred MB runs at the link rate only from pinned memory)
-char* pinned_buf(me_ctx* ctx, size_t bytes) {
-    if (ctx->pinned && ctx->pinned_bytes >= bytes) return (char*)ctx->pinned;
-    if (ctx->pinned) ME_HIP(hipHostFree(ctx->pinned));
-    ctx->pinned = nullptr, ctx->pinned_bytes = 0;
-    const size_t want = bytes + bytes / 4;  // meshes of one image size differ by their kept faces
-    ME_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
-    ctx->pinned_bytes = want;
-    return (char*)ctx->pinned;
+// pinned staging buffer of write slot `which` (the D2H copy of a few hundred MB runs at the link rate only from pinned
+// memory)
+char* pinned_buf(me_ctx* ctx, size_t bytes, int which = 0) {
+    me_ctx::WriteSlot& w = ctx->write_slots[(size_t)which];
+    if (w.pinned && w.pinned_bytes >= bytes) return (char*)w.pinned;
+    if (w.pinned) ME_HIP(hipHostFree(w.pinned));
+    w.pinned = nullptr, w.pinned_bytes = 0;
+    const size_t step = (size_t)64 << 20;
+    const size_t want = (bytes + step - 1) / step * step;
+    ME_HIP(hipHostMalloc(&w.pinned, want, hipHostMallocDefault));
+    w.pinned_bytes = want;
+    return (char*)w.pinned;
 }
 
 void write_mtl(const std::string& dest, const std::string& stem, const char* source_path) {  // output.rs:525-547
@@ -277,6 +280,46 @@ void write_mtl(const std::string& dest, const std::string& stem, const char* sou
 }
 
 }  // namespace
+
+// waits for pending write k; a failure becomes the Error of the caller that waited for it
+static void join_pending_write(me_ctx* ctx, int k) {
+    me_ctx::WriteSlot& w = ctx->write_slots[(size_t)k];
+    if (!w.active) return;
+    if (w.th.joinable()) w.th.join();
+    w.active = false;
+    if (w.code) {
+        const int32_t code = w.code;
+        const std::string msg = w.msg;
+        w.code = 0, w.msg.clear();
+        fail(code, "write-behind: %s", msg.c_str());
+    }
+}
+
+extern "C" int32_t me_ctx_set_write_behind(me_ctx* ctx, int32_t files_in_flight) {
+    if (!ctx || files_in_flight < 0 || files_in_flight > 64) return ME_ERR_BAD_ARG;
+    const int32_t rc = me_output_flush(ctx);  // nothing in flight while the slots change
+    const int n = files_in_flight == 0 ? 0 : (files_in_flight < 2 ? 2 : files_in_flight);
+    (void)hipSetDevice(ctx->device);
+    for (size_t k = (size_t)(n > 1 ? n : 1); k < ctx->write_slots.size(); ++k)
+        if (ctx->write_slots[k].pinned) (void)hipHostFree(ctx->write_slots[k].pinned);
+    ctx->write_slots.resize((size_t)(n > 1 ? n : 1));
+    ctx->write_behind = n;
+    ctx->write_next = 0;
+    return rc;
+}
+
+extern "C" int32_t me_output_flush(me_ctx* ctx) {
+    if (!ctx) return ME_ERR_BAD_ARG;
+    int32_t rc = ME_OK;
+    for (int k = 0; k < (int)ctx->write_slots.size(); ++k) {
+        try {
+            join_pending_write(ctx, k);
+        } catch (const me::Error& e) {
+            if (rc == ME_OK) ctx->last_error = e.msg, rc = e.code;
+        }
+    }
+    return rc;
+}
 
 extern "C" int32_t me_last_mesh_timing(const me_ctx* ctx, double ms_out[4], int64_t* text_bytes) {
     if (!ctx || !ms_out) return ME_ERR_BAD_ARG;
@@ -348,14 +391,37 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
             const auto t0 = now();
             const std::string stem = file_stem(dest);
             const DeviceText t = obj_text_on_device(ctx, mesh, width, height, stem, vertex_mode, vertex_colors);
-            char* host = pinned_buf(ctx, (size_t)t.bytes);
+            // write-behind: this call's text goes into the pinned buffer whose earlier write has finished (waited for
+            // here, a failure of it reported here), and a host thread writes the file while the caller moves on
+            const int slot = ctx->write_behind ? ctx->write_next : 0;
+            if (ctx->write_behind) join_pending_write(ctx, slot);
+            char* host = pinned_buf(ctx, (size_t)t.bytes, slot);
             ME_HIP(hipStreamSynchronize(ctx->stream));  // the legs are reported separately (me_last_mesh_timing)
             const auto t1 = now();
             ME_HIP(hipMemcpyAsync(host, t.dev, (size_t)t.bytes, hipMemcpyDeviceToHost, ctx->stream));
             ME_HIP(hipStreamSynchronize(ctx->stream));
             const auto t2 = now();
-            write_file_parallel(dest, host, (size_t)t.bytes);
-            if (vertex_mode == ME_VERTEX_TEXTURE) write_mtl(dest, stem, source_path);
+            if (ctx->write_behind) {
+                me_ctx::WriteSlot& w = ctx->write_slots[(size_t)slot];
+                const std::string src(source_path);
+                const size_t nbytes = (size_t)t.bytes;
+                const bool tex = vertex_mode == ME_VERTEX_TEXTURE;
+                w.active = true, w.code = 0, w.msg.clear();
+                w.th = std::thread([&w, dest, stem, src, host, nbytes, tex]() {
+                    try {
+                        write_file_parallel(dest, host, nbytes);
+                        if (tex) write_mtl(dest, stem, src.c_str());
+                    } catch (const me::Error& e) {
+                        w.code = e.code, w.msg = e.msg;
+                    } catch (const std::exception& e) {
+                        w.code = ME_ERR_IO, w.msg = e.what();
+                    }
+                });
+                ctx->write_next = (ctx->write_next + 1) % ctx->write_behind;
+            } else {
+                write_file_parallel(dest, host, (size_t)t.bytes);
+                if (vertex_mode == ME_VERTEX_TEXTURE) write_mtl(dest, stem, source_path);
+            }
             const auto t3 = now();
             ctx->mesh_ms[0] = ms(t_entry, t0), ctx->mesh_ms[1] = ms(t0, t1), ctx->mesh_ms[2] = ms(t1, t2), ctx->mesh_ms[3] = ms(t2, t3);
             ctx->mesh_bytes = t.bytes;

@@ -2,6 +2,7 @@
 #pragma once
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -140,9 +141,22 @@ struct me_ctx {
     // met a magnitude beyond 65504, common.h raise_overflow16)
     unsigned* status_dev = nullptr;
 
-    // pinned host staging buffer (the OBJ text's D2H copy, mesh_writer.hip)
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
+    // Write-behind of OBJ files (me_ctx_set_write_behind): the text of mesh call i is written to its file by a host
+    // thread while the caller goes on to image i + 1.  One slot = a pinned host staging buffer (the OBJ text's D2H
+    // copy, mesh_writer.hip) + the write that reads it; slot 0 alone serves the synchronous form.  Slots are used in
+    // turn, so at most `write_behind` writes are in flight.  A failed write is reported by the call that next waits
+    // for it (a later me_output_mesh reusing the slot, or me_output_flush).
+    int write_behind = 0;  // 0: synchronous; n >= 2: files in flight
+    struct WriteSlot {
+        void* pinned = nullptr;
+        size_t pinned_bytes = 0;
+        std::thread th;
+        bool active = false;
+        int32_t code = 0;
+        std::string msg;
+    };
+    std::vector<WriteSlot> write_slots = std::vector<WriteSlot>(1);
+    int write_next = 0;
     // legs of the last me_output_mesh(".obj") call, host wall clock: [0] mesh indexing + vertex kernels, [1] text
     // formatting kernels, [2] D2H copy of the text, [3] file write (me_last_mesh_timing)
     double mesh_ms[4] = {0, 0, 0, 0};

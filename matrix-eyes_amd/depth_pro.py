@@ -96,6 +96,15 @@ class Context:
         self._check(self.lib.me_last_mesh_timing(self._h, ms, C.byref(n)))
         return {"mesh_ms": ms[0], "format_ms": ms[1], "d2h_ms": ms[2], "file_ms": ms[3], "bytes": int(n.value)}
 
+    def set_write_behind(self, files_in_flight=2):
+        """OBJ files written by host threads behind the caller, up to `files_in_flight` at a time; 0 / False: the
+        synchronous form (matrix_eyes_hip.h me_ctx_set_write_behind)."""
+        self._check(self.lib.me_ctx_set_write_behind(self._h, int(files_in_flight)))
+
+    def output_flush(self):
+        """Waits for every pending write-behind file; raises for a failed write (me_output_flush)."""
+        self._check(self.lib.me_output_flush(self._h))
+
     def weight_arena_layout(self) -> int:
         """Hash of the weight arena's layout; contexts that exchange arenas must agree on it."""
         return int(self.lib.me_weight_arena_layout(self._h))

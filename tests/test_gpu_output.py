@@ -220,6 +220,42 @@ def test_bad_destination_is_an_error(tmp_path):
     assert rc == 7      # OutputError::Io
 
 
+def test_write_behind_files_and_deferred_errors(tmp_path):
+    """me_ctx_set_write_behind: the OBJ / MTL files written by a host thread behind the caller are the bytes of the
+    synchronous call (five meshes through the two alternating buffers), me_output_flush waits for them, and a write
+    that fails is reported by the call that next waits for it."""
+    import ctypes as C
+    ctx = m.Context(0, "f16", m.ModelConfig.tiny())
+    n = 160
+    depths = [_depth(n, seed=20 + i) for i in range(5)]
+    want = []
+    for i, d in enumerate(depths):
+        m.DepthMap(ctx, d, (n, n)).output_mesh(str(tmp_path / f"sync{i}.obj"), "photo.jpg", m.VertexMode.Texture)
+        want.append(((tmp_path / f"sync{i}.obj").read_bytes(), (tmp_path / f"sync{i}.mtl").read_bytes()))
+    ctx.set_write_behind(True)
+    for i, d in enumerate(depths):
+        m.DepthMap(ctx, d, (n, n)).output_mesh(str(tmp_path / f"behind{i}.obj"), "photo.jpg", m.VertexMode.Texture)
+    ctx.output_flush()
+    for i in range(5):
+        obj = (tmp_path / f"behind{i}.obj").read_bytes().replace(b"mtllib behind%d.mtl" % i, b"mtllib sync%d.mtl" % i)
+        assert obj == want[i][0] and (tmp_path / f"behind{i}.mtl").read_bytes() == want[i][1]
+    # a failing write: the call itself succeeds (the text reached pinned memory), the flush reports ME_ERR_IO = 7
+    d = depths[0]
+    rc = ctx.lib.me_output_mesh(ctx.handle, C.c_void_p(d.ctypes.data), n, n, n, n, b"/nonexistent-dir/x.obj", b"src", 0, None)
+    assert rc == 0
+    assert ctx.lib.me_output_flush(ctx.handle) == 7 and b"write-behind" in ctx.lib.me_last_error(ctx.handle)
+    assert ctx.lib.me_output_flush(ctx.handle) == 0          # reported once
+    # ... or the later call that has to wait for that buffer (the third after it)
+    assert ctx.lib.me_output_mesh(ctx.handle, C.c_void_p(d.ctypes.data), n, n, n, n, b"/nonexistent-dir/y.obj", b"src", 0, None) == 0
+    m.DepthMap(ctx, d, (n, n)).output_mesh(str(tmp_path / "ok1.obj"), "photo.jpg", m.VertexMode.Plain)
+    with pytest.raises(m.MatrixEyesError) as e:
+        m.DepthMap(ctx, d, (n, n)).output_mesh(str(tmp_path / "ok2.obj"), "photo.jpg", m.VertexMode.Plain)
+    assert e.value.code == 7
+    ctx.set_write_behind(False)
+    m.DepthMap(ctx, d, (n, n)).output_mesh(str(tmp_path / "sync_again.obj"), "photo.jpg", m.VertexMode.Texture)
+    assert (tmp_path / "sync_again.obj").read_bytes().replace(b"mtllib sync_again.mtl", b"mtllib sync0.mtl") == want[0][0]
+
+
 def test_config4_chain_full_size(tmp_path):
     """BASELINE configs[4] for one image at full size: model -> DepthMap -> stereogram -> textured OBJ.  The depth
     stays on the GPU from the model's output tensor through DepthMap::new (clamp + range, output.rs:44-75) into the
