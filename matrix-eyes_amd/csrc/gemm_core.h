@@ -465,7 +465,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
 // consecutive rows -- m0 is then the TILE index (image-major, tile rows, tile columns) and row t of the tile is pixel
 // (t >> 4, t & 15) of it; everything downstream sees the pixel's linear row index and coordinates as before.
 template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool PIN_CONSTS = false,
-          typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false>
+          typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false, int TILE_H = 16>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
                                               int wm, int wn, int lane, char* epi_lds,
                                               Hook after_loads = Hook(), int m_lim = -1) {
@@ -545,10 +545,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         row.b = row.y = row.x = 0;
         [[maybe_unused]] int t2_b = 0, t2_y0 = 0, t2_x0 = 0, t2_row = wm * TM + r0;  // TILE2D: tile origin, row in tile
         if constexpr (TILE2D) {
-            const int tx = p.out_W >> 4, ty = p.out_H >> 4;
+            const int tx = p.out_W >> 4, ty = p.out_H / TILE_H;  // tiles of TILE_H rows x 16 columns of pixels
             t2_b = m0 / (tx * ty);
             const int rem = m0 - t2_b * (tx * ty);
-            t2_y0 = (rem / tx) * 16;
+            t2_y0 = (rem / tx) * TILE_H;
             t2_x0 = (rem - (rem / tx) * tx) * 16;
             row.b = t2_b, row.y = t2_y0 + (t2_row >> 4), row.x = t2_x0 + (t2_row & 15);
             row.m = (row.b * p.out_H + row.y) * p.out_W + row.x;
@@ -1591,11 +1591,15 @@ void gemm_launch_8ph(const GemmParams& p, hipStream_t stream) {
 // 16-lane group of ds_read_b128 sixteen distinct (row parity, slot) pairs for kx = 0, 1 AND 2, in both k-substeps.
 __device__ __forceinline__ int halo_swizzle(int hx) { return (int)((0xcb5888u >> (3 * (hx >> 1))) & 7u); }
 
-template <typename T, int EPI>
+// TH: pixel rows of the tile (16, or 12: a 384 x 384 map is 576 tiles of 16 x 16 -- 2.25 rounds of 256 workgroups, the
+// third a quarter full -- and 768 tiles of 12 x 16: three full rounds of three quarters the work)
+template <typename T, int EPI, int TH = 16>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
+    static_assert(TH == 16 || TH == 12, "tile rows");
     constexpr int BN = 256, HW = 4, WN = 4;
-    constexpr int TM = 128, TN = 64, MI = 8, NI = 4;
-    constexpr int HALO_ROWS = 328, HALO_BYTES = HALO_ROWS * 128, HALO_PIECES = HALO_ROWS / 8;  // 41
+    constexpr int MI = TH / 2, TM = 16 * MI, TN = 64, NI = 4;  // a wave: half of the tile's pixel rows x 64 channels
+    constexpr int HALO_PX = (TH + 2) * 18;                     // 324 / 252 halo pixels
+    constexpr int HALO_ROWS = (HALO_PX + 7) / 8 * 8, HALO_BYTES = HALO_ROWS * 128, HALO_PIECES = HALO_ROWS / 8;  // 41 / 32
     constexpr int W_BYTES = BN * 128, W_BASE = 2 * HALO_BYTES;
     constexpr int B_IT = (BN / 8) / HW;  // 8 weight pieces per wave of group 0 per slab
     constexpr int MI_CH = 2;
@@ -1609,8 +1613,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2, gw = wave & 3;
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_x = p.out_W >> 4, tiles_y = p.out_H >> 4;
-    const int mtiles = (p.M >> 8);                       // 16 x 16 pixel tiles (M = B * out_H * out_W)
+    const int tiles_x = p.out_W >> 4, tiles_y = p.out_H / TH;
+    const int mtiles = p.M / (TH * 16);                  // TH x 16 pixel tiles (M = B * out_H * out_W)
     const int nbn = (p.N + BN - 1) / BN;
     const int ntiles = mtiles * nbn;
     const int nc = p.Cin / 64;                            // channel slabs; nine taps each
@@ -1626,11 +1630,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
         // the super-row / XCD walk of tile_origin over (pixel tiles) x (column tiles)
         GemmParams q = p;
         int m0;
-        tile_origin<256, BN>(q, vb, ntiles, m0, t.n0);
-        t.mt = m0 >> 8;
+        tile_origin<TH * 16, BN>(q, vb, ntiles, m0, t.n0);
+        t.mt = m0 / (TH * 16);
         const int b = t.mt / (tiles_x * tiles_y);
         const int rem = t.mt - b * (tiles_x * tiles_y);
-        const int y0 = (rem / tiles_x) * 16, x0 = (rem - (rem / tiles_x) * tiles_x) * 16;
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem - (rem / tiles_x) * tiles_x) * 16;
         t.a = (const char*)p.A + (((int64_t)b * p.in_Hp + y0) * p.in_Wp + x0) * p.Cin * 2;
         t.w = (const char*)p.W + (int64_t)t.n0 * p.K * 2;
 #pragma unroll
@@ -1653,7 +1657,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     // halo piece `pc` (8 pixels) of channel slab c into halo slot `slot` (group 1)
     auto stage_halo_piece = [&](const Tile& t, int c, int pc, int slot) {
         int r = pc * 8 + srow;
-        r = r < 324 ? r : 323;                              // the 4 pad rows repeat the last pixel (never read)
+        r = r < HALO_PX ? r : HALO_PX - 1;                  // the 4 pad rows repeat the last pixel (never read)
         const int hy = (r * 3641) >> 16;                    // r / 18 for r < 324
         const int hx = r - hy * 18;
         const int chunk = sslot ^ halo_swizzle(hx);         // the halo image's swizzle goes by the pixel's COLUMN
@@ -1723,7 +1727,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
                 }
                 const char* sw = smem + W_BASE + ws * W_BYTES + w_rd;
                 const char* sa = smem + hs * HALO_BYTES;
-                const char* sa_tap = sa + (wm * 8 + ky) * (18 * 128);
+                const char* sa_tap = sa + (wm * MI + ky) * (18 * 128);
                 const int a0 = kx == 0 ? a_col[0] : (kx == 1 ? a_col[1] : a_col[2]);
                 const int a1 = a0 ^ 64;
                 constexpr int G = 2 * MI;
@@ -1782,7 +1786,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
         // ws / hs now name the next tile's first weight slab / halo; the slots consumed last are the scratch
         {
             char* scr = (group == 0 ? smem + (hs ^ 1) * HALO_BYTES : smem + W_BASE + (ws ^ 1) * W_BYTES) + gw * SCR;
-            gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true, NoHook, 0, true>(p, acc, cur.mt, cur.n0, wm, wn, lane, scr);
+            gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true, NoHook, 0, true, TH>(p, acc, cur.mt, cur.n0, wm, wn, lane, scr);
         }
         if (!has_next) break;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1794,14 +1798,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int TH = 16>
 void conv_halo_launch(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * 328 * 128 + 2 * 256 * 128;
-    ME_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out_H % 16 == 0 && p.out_W % 16 == 0 && p.Cin % 64 == 0 &&
-                 p.M % 256 == 0,
+    constexpr int smem = 2 * (((TH + 2) * 18 + 7) / 8 * 8) * 128 + 2 * 256 * 128;
+    ME_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out_H % TH == 0 && p.out_W % 16 == 0 && p.Cin % 64 == 0 &&
+                 p.M % (TH * 16) == 0,
              ME_ERR_BAD_SHAPE, "conv (halo tile): %dx%d stride %d on %dx%d, Cin %d", p.KH, p.KW, p.stride, p.out_H, p.out_W,
              p.Cin);
-    auto kern = conv_halo_kernel<T, EPI>;
+    auto kern = conv_halo_kernel<T, EPI, TH>;
     static PerDeviceOnce once;
     const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1812,7 +1816,7 @@ void conv_halo_launch(const GemmParams& p, hipStream_t stream) {
         r -= r % 8;
         return r < 8 ? 8 : r;
     });
-    const int64_t ntiles = (int64_t)(p.M / 256) * cdiv(p.N, 256);
+    const int64_t ntiles = (int64_t)(p.M / (TH * 16)) * cdiv(p.N, 256);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "conv grid %lld out of range", (long long)ntiles);
     const int64_t grid = ntiles < resident ? ntiles : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
@@ -2012,6 +2016,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 9:                                                                       \
                 if constexpr (AMODE == A_CONV && EPI == EPI_STORE)                        \
                     conv_halo_launch<T, EPI>(p, stream);                                  \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
+                break;                                                                    \
+            case 11: /* the halo tile on 12 x 16 pixels (three full rounds of a 384 x 384 map instead of 2.25) */ \
+                if constexpr (AMODE == A_CONV && EPI == EPI_STORE)                        \
+                    conv_halo_launch<T, EPI, 12>(p, stream);                              \
                 else                                                                      \
                     fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
                 break;                                                                    \

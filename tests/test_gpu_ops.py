@@ -373,6 +373,7 @@ def test_conv2d(dtype, case, cfg):
     dict(B=1, H=16, W=16, Cin=128, Cout=256, relu=True),
     dict(B=1, H=272, W=272, Cin=128, Cout=256, res=True),       # 289 pixel tiles: workgroups walk on to a second tile
     dict(B=3, H=96, W=112, Cin=192, Cout=256, res=True, relu=True),
+    dict(B=1, H=384, W=384, Cin=64, Cout=256, res=True, relu=True),   # the decoder's 384 x 384 level: 768 tiles of 12 x 16
 ])
 def test_conv3x3_halo_tile(dtype, case):
     """Tile config 9 (gemm_core.h conv_halo_kernel): 16 x 16 pixel tiles whose 18 x 18 halo is staged once per 64 input
@@ -412,6 +413,15 @@ def test_conv3x3_halo_tile(dtype, case):
     # so the halo tile and the implicit-GEMM tile agree bit for bit -- the result does not depend on which tile the
     # problem size selects
     assert torch.equal(outs[9][0], outs[0][0]) and torch.equal(outs[9][1], outs[0][1])
+    if H % 12 == 0:
+        # tile config 11: the halo tile on 12 x 16 pixels (chosen where it fills the rounds of 256 workgroups better)
+        out32 = torch.empty_like(outs[9][0])
+        out16 = torch.zeros_like(outs[9][1])
+        torch.cuda.synchronize()
+        _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, 3, 1, ptr(bias_d), ptr(res), ptr(res2),
+                                         ptr(out32), ptr(out16), 1, act, 0, 11))
+        ctx.synchronize()
+        assert torch.equal(out32, outs[9][0]) and torch.equal(out16, outs[9][1])
     # a repeated launch of the halo tile reproduces itself bit for bit
     out32 = torch.empty_like(outs[9][0])
     out16 = torch.zeros_like(outs[9][1])
