@@ -26,10 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
           ["TCC_HIT_sum", "TCC_MISS_sum"], ["TCC_REQ_sum", "TCC_EA0_RDREQ_sum"]]
-# the launches of one step at one image: qkv on tile config 0 (3.98 rounds), fc1 / proj / fc2 on the 352-row tile (config
-# 10: four rounds / one exact round, pipeline.hip tall_tile_wins); the 3x3 convolutions on the halo tile (config 9).
+# the launches of one step at one image: qkv / fc1 / proj / fc2 on the 352-row tile (config 10: three / four / one exact
+# rounds, pipeline.hip tall_tile_wins); the 3x3 convolutions on the halo tile (config 9).
 # The round-3 short-tail launches (ME_GEMM_TALL=0) stay selectable: fc1_tail:7 proj_tail:7 fc2_tail:7 with fc1:0 ...
-DEFAULT = ["qkv:0", "fc1_tall:10", "proj_tall:10", "fc2_tall:10", "conv768:9", "attn:0"]
+DEFAULT = ["qkv_tall:10", "fc1_tall:10", "proj_tall:10", "fc2_tall:10", "conv768:9", "attn:0"]
 CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "160x128x64/4w", 4: "64x64x64/4w-ring6",
              5: "192x256x64/8w-pp", 6: "256x256x64/8w-8ph", 7: "96x256x64/8w-pp", 8: "128x256x64/8w-ring3",
              9: "16x16px-x256x64/8w-halo", 10: "352x256x64/8w-pp"}
@@ -37,7 +37,7 @@ CFG_NAMES = {0: "256x256x64/8w-pp", 1: "128x128x64/4w", 2: "64x64x64/4w", 3: "16
 SHAPES = {"qkv": ("qkv", 3072, 1024, 21760), "fc1": ("fc1", 4096, 1024, 20480), "fc1_tail": ("fc1", 4096, 1024, 1280),
           "proj": ("proj", 1024, 1024, 16384), "proj_tail": ("proj", 1024, 1024, 5376),
           "fc2": ("fc2", 1024, 4096, 16384), "fc2_tail": ("fc2", 1024, 4096, 5376),
-          "fc1_tall": ("fc1", 4096, 1024, 21760), "proj_tall": ("proj", 1024, 1024, 21760),
+          "qkv_tall": ("qkv", 3072, 1024, 21760), "fc1_tall": ("fc1", 4096, 1024, 21760), "proj_tall": ("proj", 1024, 1024, 21760),
           "fc2_tall": ("fc2", 1024, 4096, 21760)}
 SHAPES8 = {"qkv8": (3072, 1024), "fc1_8": (4096, 1024), "fc2_8": (1024, 4096)}   # MX fp8 operands
 PROBE_M = 21760
