@@ -231,6 +231,8 @@ struct GemmParams {
     // Context status word (me_status_flags): bit 0 is set when an f16 operand store met a magnitude beyond 65504
     // (gemm_launch fills it in from the calling context)
     unsigned* status;
+    // tile rows of an XCD's patch in the tile walk (gemm_core.h tile_origin); 0: 8
+    int32_t patch_rows;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).

@@ -245,7 +245,7 @@ __device__ __forceinline__ void seg_tile_rows(const GemmParams& p, int rt, int& 
 // 44 % L2 misses on the fc1 shape, profiles/r01_pmc_gemm.md).
 template <int BM, int BN, bool SEG = false>
 __device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0, int* m_lim = nullptr) {
-    constexpr int GM = 8;
+    const int GM = SEG && p.patch_rows ? p.patch_rows : 8;
     const int nbm = SEG ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);  // bijective
