@@ -62,9 +62,9 @@ ProfScope::~ProfScope() {
 // Tile configurations (the ids are what me_op_* take as tile_cfg)
 static const char* kCfgNames[] = {"256x256x64/8w-pp", "128x128x64/4w", "64x64x64/4w", "160x128x64/4w",
                                   "64x64x64/4w-ring6", "192x256x64/8w-pp", "256x256x64/8w-8ph", "96x256x64/8w-pp",
-                                  "128x256x64/8w-ring3", "16x16px-x256x64/8w-halo", "352x256x64/8w-pp", "12x16px-x256x64/8w-halo"};
+                                  "128x256x64/8w-ring3", "16x16px-x256x64/8w-halo", "352x256x64/8w-pp", "12x16px-x256x64/8w-halo", "16x16px-x128x64/8w-halo"};
 enum { CFG_PP256 = 0, CFG_128 = 1, CFG_64 = 2, CFG_160 = 3, CFG_RING64 = 4, CFG_PP192 = 5, CFG_8PH = 6, CFG_PP96 = 7,
-       CFG_RING128 = 8, CFG_HALO = 9, CFG_PP352 = 10, CFG_HALO12 = 11, CFG_COUNT = 12 };
+       CFG_RING128 = 8, CFG_HALO = 9, CFG_PP352 = 10, CFG_HALO12 = 11, CFG_HALO_N128 = 12, CFG_COUNT = 13 };
 int gemm_num_configs() { return CFG_COUNT; }
 const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < CFG_COUNT ? kCfgNames[cfg] : "?"; }
 
@@ -197,6 +197,16 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
         }
     }
     if (cfg == CFG_HALO) ME_CHECK(halo_fits, ME_ERR_BAD_SHAPE, "conv: the halo tile takes 3x3 stride-1 convolutions on maps of 16-pixel multiples, N a multiple of 256");
+    // N = 128 (the head's first convolution, 256 -> 128 at 768 x 768): the halo tile with 128 channels where the
+    // 128x128 implicit-GEMM tile would have been chosen on a map of at least a round of pixel tiles
+    const bool halo128_fits = amode == A_CONV && epi == EPI_STORE && p.KH == 3 && p.KW == 3 && p.stride == 1 &&
+                              p.out_H % 16 == 0 && p.out_W % 16 == 0 && p.N % 128 == 0;
+    static const bool halo128_on = !(getenv("ME_CONV_HALO128") && atoi(getenv("ME_CONV_HALO128")) == 0);
+    if (force_cfg < 0 && halo_on && halo128_on && halo128_fits && p.N % 256 != 0 && cfg == CFG_128 &&
+        (int64_t)(p.M / 256) * (p.N / 128) >= 256)
+        cfg = CFG_HALO_N128;
+    if (cfg == CFG_HALO_N128)
+        ME_CHECK(halo128_fits, ME_ERR_BAD_SHAPE, "conv: the 128-channel halo tile takes 3x3 stride-1 convolutions on maps of 16-pixel multiples, N a multiple of 128");
     if (cfg == CFG_HALO12)
         ME_CHECK(amode == A_CONV && epi == EPI_STORE && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out_H % 12 == 0 &&
                      p.out_W % 16 == 0 && p.N % 256 == 0,
@@ -204,7 +214,7 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     if ((cfg == CFG_PP256 || cfg == CFG_PP192 || cfg == CFG_8PH || cfg == CFG_PP96 || cfg == CFG_PP352) && p.K < 128) cfg = CFG_128;  // they prefetch two slabs ahead
     {
         // (the 352-row tile lays its row tiles out per segment, gemm_core.h seg_tile_rows: any boundary will do)
-        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64, 192, 256, 96, 128, 256, 1, 1};
+        static const int kTileRows[CFG_COUNT] = {256, 128, 64, 160, 64, 192, 256, 96, 128, 256, 1, 1, 256};
         const int bm = epi == EPI_HEAD_FINAL ? 256 : kTileRows[cfg];
         ME_CHECK(p.seg1 % bm == 0 && p.seg2 % bm == 0 && (p.seg2 == 0 || p.seg2 > p.seg1), ME_ERR_BAD_ARG,
                  "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);

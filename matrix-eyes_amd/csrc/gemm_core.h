@@ -1593,11 +1593,13 @@ __device__ __forceinline__ int halo_swizzle(int hx) { return (int)((0xcb5888u >>
 
 // TH: pixel rows of the tile (16, or 12: a 384 x 384 map is 576 tiles of 16 x 16 -- 2.25 rounds of 256 workgroups, the
 // third a quarter full -- and 768 tiles of 12 x 16: three full rounds of three quarters the work)
-template <typename T, int EPI, int TH = 16>
+// BN: output channels per tile (256, or 128 for the head's 256 -> 128 convolution: a wave then owns 32 channels)
+template <typename T, int EPI, int TH = 16, int BN = 256>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     static_assert(TH == 16 || TH == 12, "tile rows");
-    constexpr int BN = 256, HW = 4, WN = 4;
-    constexpr int MI = TH / 2, TM = 16 * MI, TN = 64, NI = 4;  // a wave: half of the tile's pixel rows x 64 channels
+    static_assert(BN == 256 || BN == 128, "tile channels");
+    constexpr int HW = 4, WN = 4;
+    constexpr int MI = TH / 2, TM = 16 * MI, TN = BN / WN, NI = TN / 16;  // a wave: half of the tile's pixel rows x 64 (32) channels
     constexpr int HALO_PX = (TH + 2) * 18;                     // 324 / 252 halo pixels
     constexpr int HALO_ROWS = (HALO_PX + 7) / 8 * 8, HALO_BYTES = HALO_ROWS * 128, HALO_PIECES = HALO_ROWS / 8;  // 41 / 32
     constexpr int W_BYTES = BN * 128, W_BASE = 2 * HALO_BYTES;
@@ -1798,14 +1800,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int EPI, int TH = 16>
+template <typename T, int EPI, int TH = 16, int BN = 256>
 void conv_halo_launch(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * (((TH + 2) * 18 + 7) / 8 * 8) * 128 + 2 * 256 * 128;
+    constexpr int smem = 2 * (((TH + 2) * 18 + 7) / 8 * 8) * 128 + 2 * BN * 128;
     ME_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out_H % TH == 0 && p.out_W % 16 == 0 && p.Cin % 64 == 0 &&
                  p.M % (TH * 16) == 0,
              ME_ERR_BAD_SHAPE, "conv (halo tile): %dx%d stride %d on %dx%d, Cin %d", p.KH, p.KW, p.stride, p.out_H, p.out_W,
              p.Cin);
-    auto kern = conv_halo_kernel<T, EPI, TH>;
+    auto kern = conv_halo_kernel<T, EPI, TH, BN>;
     static PerDeviceOnce once;
     const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1816,7 +1818,7 @@ void conv_halo_launch(const GemmParams& p, hipStream_t stream) {
         r -= r % 8;
         return r < 8 ? 8 : r;
     });
-    const int64_t ntiles = (int64_t)(p.M / (TH * 16)) * cdiv(p.N, 256);
+    const int64_t ntiles = (int64_t)(p.M / (TH * 16)) * cdiv(p.N, BN);
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "conv grid %lld out of range", (long long)ntiles);
     const int64_t grid = ntiles < resident ? ntiles : resident;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
@@ -2016,6 +2018,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
             case 9:                                                                       \
                 if constexpr (AMODE == A_CONV && EPI == EPI_STORE)                        \
                     conv_halo_launch<T, EPI>(p, stream);                                  \
+                else                                                                      \
+                    fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
+                break;                                                                    \
+            case 12: /* the halo tile with 128 output channels (the head's 256 -> 128 convolution at 768 x 768) */ \
+                if constexpr (AMODE == A_CONV && EPI == EPI_STORE)                        \
+                    conv_halo_launch<T, EPI, 16, 128>(p, stream);                         \
                 else                                                                      \
                     fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
                 break;                                                                    \

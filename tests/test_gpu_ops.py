@@ -374,6 +374,8 @@ def test_conv2d(dtype, case, cfg):
     dict(B=1, H=272, W=272, Cin=128, Cout=256, res=True),       # 289 pixel tiles: workgroups walk on to a second tile
     dict(B=3, H=96, W=112, Cin=192, Cout=256, res=True, relu=True),
     dict(B=1, H=384, W=384, Cin=64, Cout=256, res=True, relu=True),   # the decoder's 384 x 384 level: 768 tiles of 12 x 16
+    dict(B=2, H=48, W=80, Cin=128, Cout=128, relu=True, halo=12),     # tile config 12: 128 output channels per tile
+    dict(B=1, H=272, W=272, Cin=64, Cout=384, res=True, halo=12),     # 289 pixel tiles x 3 channel tiles
 ])
 def test_conv3x3_halo_tile(dtype, case):
     """Tile config 9 (gemm_core.h conv_halo_kernel): 16 x 16 pixel tiles whose 18 x 18 halo is staged once per 64 input
@@ -396,7 +398,8 @@ def test_conv3x3_halo_tile(dtype, case):
         ref = ref + res.double().cpu() + res2.double().cpu()
     ref16 = F.relu(ref) if act else ref
     outs = {}
-    for cfg in (9, -1, 0):
+    HALO = case.get("halo", 9)
+    for cfg in (HALO, -1, 0):
         out32 = torch.empty(B * H * W, Cout, dtype=torch.float32, device="cuda")
         out16 = torch.zeros(B, H + 2, W + 2, Cout, dtype=TORCH16[dtype], device="cuda")
         torch.cuda.synchronize()
@@ -412,8 +415,9 @@ def test_conv3x3_halo_tile(dtype, case):
     # every convolution tile walks K in the same order (input-channel slab outermost, taps inside: gemm_core.h SlabWalk),
     # so the halo tile and the implicit-GEMM tile agree bit for bit -- the result does not depend on which tile the
     # problem size selects
+    outs[9] = outs[HALO]
     assert torch.equal(outs[9][0], outs[0][0]) and torch.equal(outs[9][1], outs[0][1])
-    if H % 12 == 0:
+    if H % 12 == 0 and HALO == 9:
         # tile config 11: the halo tile on 12 x 16 pixels (chosen where it fills the rounds of 256 workgroups better)
         out32 = torch.empty_like(outs[9][0])
         out16 = torch.zeros_like(outs[9][1])
@@ -427,7 +431,7 @@ def test_conv3x3_halo_tile(dtype, case):
     out16 = torch.zeros_like(outs[9][1])
     torch.cuda.synchronize()
     _check(ctx, ctx.lib.me_op_conv2d(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cout, 3, 1, ptr(bias_d), ptr(res), ptr(res2),
-                                     ptr(out32), ptr(out16), 1, act, 0, 9))
+                                     ptr(out32), ptr(out16), 1, act, 0, HALO))
     ctx.synchronize()
     assert torch.equal(out32, outs[9][0]) and torch.equal(out16, outs[9][1])
 
