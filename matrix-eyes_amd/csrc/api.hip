@@ -923,12 +923,17 @@ int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, cons
                               void* out16, float* x32, int32_t act, int32_t tile_cfg) {
     ME_API_BEGIN(ctx)
     ME_CHECK(A16 && W16 && bias && (out16 || x32), ME_ERR_BAD_ARG, "me_op_linear_segments: null pointer");
+    ME_CHECK(W16[0] && (seg1 == 0 || W16[1]) && (seg2 == 0 || W16[2]), ME_ERR_BAD_ARG,
+             "me_op_linear_segments: a row segment without weights");
+    ME_CHECK(seg1 >= 0 && seg2 >= 0 && seg1 <= M && seg2 <= M && (seg2 == 0 || (seg1 > 0 && seg2 > seg1)), ME_ERR_BAD_ARG,
+             "me_op_linear_segments: segments %d / %d of %d rows", seg1, seg2, M);
     GemmParams p = GemmParams();
     p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16[0], p.bias = bias[0], p.ldc = N;
     p.seg1 = seg1, p.seg2 = seg2, p.W_s1 = W16[1], p.bias_s1 = bias[1], p.W_s2 = W16[2], p.bias_s2 = bias[2];
     p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
     if (x32) {
-        ME_CHECK(gamma, ME_ERR_BAD_ARG, "me_op_linear_segments: the residual form takes gamma");
+        ME_CHECK(gamma && gamma[0] && (seg1 == 0 || gamma[1]) && (seg2 == 0 || gamma[2]), ME_ERR_BAD_ARG,
+                 "me_op_linear_segments: the residual form takes gamma for every segment");
         p.gamma = gamma[0], p.gamma_s1 = gamma[1], p.gamma_s2 = gamma[2], p.res32 = x32, p.out32 = x32;
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, ctx->stream, tile_cfg);
     } else {

@@ -233,6 +233,26 @@ def test_tall_tile_352(dtype, resid, shape):
         assert torch.equal(got, same)
 
 
+def test_linear_segments_argument_errors():
+    """me_op_linear_segments: a segment without weights, or boundaries out of order, is ME_ERR_BAD_ARG, not a device fault"""
+    import ctypes as C
+    ctx = ctx_for("tiny", "f16")
+    a = dev16(torch.randn(512, 128), "f16")
+    w = dev16(torch.randn(256, 128), "f16")
+    b = torch.zeros(256, device="cuda")
+    out = torch.empty(512, 256, dtype=torch.float16, device="cuda")
+    one = (C.c_void_p * 3)(w.data_ptr(), None, None)
+    bias = (C.c_void_p * 3)(b.data_ptr(), b.data_ptr(), b.data_ptr())
+    call = lambda s1, s2, ws: ctx.lib.me_op_linear_segments(ctx.handle, 512, 256, 128, ptr(a), s1, s2, ws, bias, None, ptr(out), None, 0, 10)
+    assert call(0, 0, one) == 0
+    assert call(256, 0, one) == 1            # segment 1 has no weights
+    both = (C.c_void_p * 3)(w.data_ptr(), w.data_ptr(), None)
+    assert call(256, 0, both) == 0
+    assert call(256, 128, both) == 1         # seg2 <= seg1
+    assert call(600, 0, both) == 1           # beyond M
+    ctx.synchronize()
+
+
 def test_tall_tile_352_at_the_step_shapes():
     """proj / fc2 / fc1 of one 1536x1536 image (M = 21760 in segments of 768 / 768 / 20224 rows): one exact round of
     256 tall tiles (proj, fc2), four rounds (fc1); bit-identical to the 256-row tile."""
