@@ -35,6 +35,19 @@ impl HipDevice {
         Ok(HipDevice { ctx, weights_loaded: std::cell::Cell::new(false) })
     }
 
+    /// A loop over many images (main.rs called per file of a batch): `.obj` files are written behind the caller by up
+    /// to `files_in_flight` host threads while the GPU works on the next image; `flush_outputs` before the files are
+    /// read.  0 restores the reference's form (output_mesh returns with the file written).
+    pub fn set_write_behind(&self, files_in_flight: i32) -> Result<(), HipError> {
+        self.check(unsafe { ffi::me_ctx_set_write_behind(self.ctx, files_in_flight) })
+    }
+
+    /// Waits for every file a write-behind `output_mesh` has handed to a host thread; a failed write surfaces here
+    /// (or at the next `output_mesh` that has to wait for it) as the OutputError::Io it would have been.
+    pub fn flush_outputs(&self) -> Result<(), HipError> {
+        self.check(unsafe { ffi::me_output_flush(self.ctx) })
+    }
+
     fn check(&self, rc: i32) -> Result<(), HipError> {
         if rc == ffi::ME_OK {
             Ok(())
