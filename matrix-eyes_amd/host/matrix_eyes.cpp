@@ -69,6 +69,14 @@ Device::~Device() {
     if (ctx_) me_ctx_destroy(ctx_);
 }
 
+void Device::set_write_behind(int files_in_flight) const {
+    if (me_ctx_set_write_behind(ctx_, files_in_flight) != ME_OK) throw output::OutputError(me_last_error(ctx_));
+}
+
+void Device::flush_outputs() const {
+    if (me_output_flush(ctx_) != ME_OK) throw output::OutputError(me_last_error(ctx_));  // OutputError::Io of a file written behind
+}
+
 // ---- DepthProModelLoader -----------------------------------------------------------------------------
 void DepthProModelLoader::ensure_loaded(const Device& device) const {
     if (device.weights_loaded_) return;

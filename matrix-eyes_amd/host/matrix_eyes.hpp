@@ -50,6 +50,10 @@ public:
     Device& operator=(const Device&) = delete;
     me_ctx* ctx() const { return ctx_; }
     int image_size() const { return image_size_; }  // IMG_SIZE unless a test model is selected
+    // a caller that writes one mesh per image of a batch: .obj files written behind it by up to `files_in_flight` host
+    // threads (me_ctx_set_write_behind); flush_outputs() before the files are read -- a failed write surfaces there
+    void set_write_behind(int files_in_flight) const;
+    void flush_outputs() const;
 
 private:
     me_ctx* ctx_ = nullptr;
