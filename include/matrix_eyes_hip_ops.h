@@ -29,6 +29,14 @@ int32_t me_op_linear_residual(me_ctx* ctx, int32_t M, int32_t N, int32_t K, cons
 /* Attention (vit.rs:58-75): qkv16 [windows*tokens][3*heads*64] -> out16 [windows*tokens][heads*64] */
 int32_t me_op_attention(me_ctx* ctx, const void* qkv16, void* out16, int32_t windows, int32_t tokens,
                         int32_t heads);
+/* The form the forward pass runs (pipeline.hip): the qkv linear writes its first `qcols` output columns (Q) multiplied
+   by `qscale` = 1/sqrt(64) * log2(e) -- out16 = round16((A . W^T + bias) * qscale) there, one rounding -- and the
+   attention kernel takes that Q as it is (its softmax runs on exp2 with the reference point inside the MFMA
+   accumulator).  me_op_attention scales a plain Q itself, with a second rounding. */
+int32_t me_op_linear_scaled_cols(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, const void* W16,
+                                 const float* bias, void* out16, int32_t qcols, float qscale, int32_t tile_cfg);
+int32_t me_op_attention_prescaled(me_ctx* ctx, const void* qkv16, void* out16, int32_t windows, int32_t tokens,
+                                  int32_t heads);
 /* LayerNorm (vit.rs:165,168,343): x32 [rows][dim] -> y16 and/or y32 */
 int32_t me_op_layernorm(me_ctx* ctx, const float* x32, const float* weight, const float* bias,
                         void* y16, float* y32, int64_t rows, int32_t dim, float eps);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "me_op_linear": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32]),
     "me_op_linear_residual": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
     "me_op_attention": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    "me_op_attention_prescaled": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    "me_op_linear_scaled_cols": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _i32]),
     "me_op_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
     "me_op_conv2d": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                             _vp, _vp, _i32, _i32, _i32, _i32]),

@@ -802,6 +802,26 @@ int32_t me_op_attention(me_ctx* ctx, const void* qkv16, void* out16, int32_t win
     ME_API_END(ctx)
 }
 
+int32_t me_op_attention_prescaled(me_ctx* ctx, const void* qkv16, void* out16, int32_t windows, int32_t tokens,
+                                  int32_t heads) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(qkv16 && out16, ME_ERR_BAD_ARG, "me_op_attention_prescaled: null pointer");
+    attention_launch(qkv16, out16, windows, tokens, heads, ctx->dtype, ctx->stream, nullptr, nullptr, nullptr, 0, true);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_linear_scaled_cols(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, const void* W16,
+                                 const float* bias, void* out16, int32_t qcols, float qscale, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(A16 && W16 && bias && out16, ME_ERR_BAD_ARG, "me_op_linear_scaled_cols: null pointer");
+    GemmParams p = GemmParams();
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16, p.bias = bias, p.out16 = out16, p.ldc = N;
+    p.qcols = qcols, p.qscale = qscale;
+    gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
 int32_t me_op_layernorm(me_ctx* ctx, const float* x32, const float* weight, const float* bias,
                         void* y16, float* y32, int64_t rows, int32_t dim, float eps) {
     ME_API_BEGIN(ctx)

@@ -58,6 +58,9 @@ constexpr int TILE_BYTES = KT * 128;
 // product kernel.  [0] DMA wait + barrier, [1] staging issue, [2] S = K Q^T and the running max, [3] rescale +
 // exponentials, [4] P V, [5] closing LDS wait, [6] everything (prologue and epilogue included).
 __device__ unsigned long long* g_att_stamps = nullptr;
+// timing-only ablations of attention2_kernel (results are wrong): 1 = no restaging and no barrier after the first
+// tile, 2 = no exponentials, 4 = no P V / row-sum MFMAs, 8 = no S MFMAs
+__device__ int g_att_mode = 0;
 #define ATT_PH(i)                                                  \
     do {                                                           \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
@@ -391,6 +394,380 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------
+// The kernel of the forward pass (Q pre-scaled by the qkv linear's epilogue, GemmParams::qcols): the same decomposition
+// as the kernel above (one workgroup = 4 waves = 128 queries of one (window, head), 64-key K/V tiles through a two-slot
+// LDS-DMA ring, S^T = K Q^T with the S^T accumulator as the B operand of O^T += V^T P^T) with the VECTOR work per score
+// cut from 4 instructions to 2.2 (PMC: 14.7 -> 7.5 VALU instructions per MFMA):
+//   * the softmax reference point lives in the matrix pipe.  Q arrives multiplied by scale * log2(e), and the first
+//     MFMA of a score block takes C = -m', sixteen registers that all hold the negated reference point of the lane's
+//     query in exp2 units: S' = K Qc^T - m' needs no FMA per score, p = exp2(S') directly;
+//   * the reference point follows the running maximum only when some score passes it by more than 2^defer_thr (T13 of
+//     the guide; the first tile always sets it): with 32 queries to a wave SOME maximum grows in nearly every tile, and
+//     the rescale (60 vector instructions: O, l, the score block and C) ran every tile -- as it does in the kernel above;
+//   * the row sums come from the matrix pipe too: one more MFMA per 16 keys with an all-ones A operand adds up the
+//     P^T operand over its keys (all 32 rows of that product are the same sum; both lane halves included, so there is
+//     no cross-half exchange at the end, and l is the sum of the ROUNDED probabilities that the numerator uses);
+//   * staging addresses are per-lane constants beside a uniform base that walks with the tile (the ragged last tile
+//     computes its clamped rows when it is staged, once).
+// Per tile and wave: 32 v_exp_f32, 16 v_max3_f32, 16 v_cvt_pk, 20 MFMAs (8 + 8 + 4).  168 VGPRs: three waves per SIMD.
+// Measured (tools/attn_ab.py, 37 windows, one process, interleaved): 82 us against 88 - 91 us for the kernel above
+// (614 against 554 - 570 TFLOP/s on the real FLOPs) -- half the vector instructions buy 8 %: at three or four waves per SIMD a
+// wave's tile is a serial chain (K reads -> 8 MFMAs -> max -> exp -> cvt -> 12 MFMAs) and its lifetime, 4800 cycles per tile
+// beside two or three others, barely moves with the instruction count (phase stamps and timing-only ablations:
+// profiles/r04_attention_ablations.txt).  What that points at is two query blocks per wave (the second block's MFMAs
+// under the first one's softmax), not fewer instructions.
+template <typename T, int MINW>
+__global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                               int tokens, int heads, int ngroups,
+                                                               RowSegs segs, uint8_t* __restrict__ out8,
+                                                               uint8_t* __restrict__ out8_scale, int64_t out8_mt,
+                                                               float defer_thr) {
+    typedef typename Mfma32<T>::frag frag;
+    constexpr int NSLOT = 2;
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bid = blockIdx.x;
+#ifdef ME_ATT_STAMPS
+    // [0] DMA wait + barrier, [1] staging issue, [2] S' = K Qc^T, [3] max + branch, [4] exponentials, [5] P V + row sums,
+    // [6] everything; [7] prologue (up to the first tile)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    unsigned long long t_last = t_begin;
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int C = heads * 64;
+    const int ldq = 3 * C;
+    const int nqb = (tokens + 127) >> 7;
+    const int xcd = bid & 7, slot0 = bid >> 3;
+    const int group = xcd + 8 * (slot0 / nqb);  // = win * heads + head
+    const int qblk = slot0 - (slot0 / nqb) * nqb;
+    if (group >= ngroups) return;  // uniform: the whole workgroup leaves before any barrier
+    const int win = group / heads, head = group - win * heads;
+    const int q0 = qblk * 128 + wave * 32;
+    int64_t row0 = (int64_t)win * tokens;
+    if (segs.seg1 && win >= segs.win0)
+        row0 = win < segs.win0 + segs.win1 ? segs.seg1 + (int64_t)(win - segs.win0) * tokens
+                                           : segs.seg2 + (int64_t)(win - segs.win0 - segs.win1) * tokens;
+    const T* qbase = qkv + head * 64;
+    const T* kbase = qkv + C + head * 64;
+    const T* vbase = qkv + 2 * C + head * 64;
+
+    // K/V staging by LDS-DMA (see the kernel above): wave w stages pieces 2w and 2w + 1 of K and of V
+    const int st_row = lane >> 3, st_slot = lane & 7;
+    const unsigned row_bytes = (unsigned)ldq * 2u;
+    unsigned koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (2 * wave + i) * 8 + st_row;
+        koff[i] = (unsigned)rr * row_bytes + ((st_slot ^ ((rr >> 1) & 7)) << 4);
+        voff[i] = (unsigned)rr * row_bytes + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4);
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    const char* kwin = uniform_ptr((const char*)(kbase + row0 * ldq));
+    const char* vwin = uniform_ptr((const char*)(vbase + row0 * ldq));
+    const int nkt = (tokens + KT - 1) / KT;
+    auto stage = [&](int kt, int slot) {  // 4 LDS-DMA instructions per wave and tile
+        const unsigned dst = smem_base + slot * (2 * TILE_BYTES) + (2 * wave) * 1024;
+        const char* kt_k = uniform_ptr(kwin + (size_t)kt * KT * row_bytes);
+        const char* kt_v = uniform_ptr(vwin + (size_t)kt * KT * row_bytes);
+        if ((kt + 1) * KT <= tokens) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                glds16_raw(kt_k, koff[i], dst + i * 1024);
+                glds16_raw(kt_v, voff[i], dst + TILE_BYTES + i * 1024);
+            }
+        } else {  // the ragged last tile: rows past the end read the last row (masked or unused below)
+            const int last = tokens - 1 - kt * KT;  // >= 0
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rr = (2 * wave + i) * 8 + st_row;
+                const unsigned rowb = (unsigned)(rr < last ? rr : last) * row_bytes;
+                glds16_raw(kt_k, rowb + ((st_slot ^ ((rr >> 1) & 7)) << 4), dst + i * 1024);
+                glds16_raw(kt_v, rowb + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4), dst + TILE_BYTES + i * 1024);
+            }
+        }
+    };
+
+    const int k_rd = r * 128;
+    const int k_swz = (r >> 1) & 7;
+    const int il = lane & 15;
+    const int v_qrow = il >> 2, v_p = il & 3;
+    const int v_dhalf = (lane >> 4) & 1;
+
+    f32x16 o[2], lsum, negm;
+    o[0] = f32x16{0};
+    o[1] = f32x16{0};
+    lsum = f32x16{0};
+    negm = f32x16{0};
+    float m_run = 0.f;  // the running maximum (exp2 units); negm == -m_run in all sixteen registers
+    frag ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+
+    stage(0, 0);
+
+    // Q fragments: B operand, lane holds Qc[q0 + r][16 s + 8 h + 0..7], Qc = Q * scale * log2(e)
+    frag qf[4];
+    {
+        int q = q0 + r;
+        q = q < tokens ? q : tokens - 1;
+        const T* qp = qbase + (row0 + q) * ldq + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+        // settle these loads here (see the kernel above)
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 t = __builtin_bit_cast(i32x4, qf[s]);
+            asm volatile("" : "+v"(t));
+            qf[s] = __builtin_bit_cast(frag, t);
+        }
+    }
+
+    const bool active = q0 < tokens;
+    int slot = 0;
+    auto tile = [&](int kt, auto first_tag, auto tail_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool TAIL = decltype(tail_tag)::value;
+#ifdef ME_ATT_STAMPS
+        if (FIRST) ph[7] = __builtin_amdgcn_s_memtime() - t_begin;
+        t_last = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef ME_ATT_STAMPS
+        const int abl = __builtin_amdgcn_readfirstlane(g_att_mode);
+        if (!(abl & 1) || FIRST) {
+#endif
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ATT_PH(0);
+        if (kt + 1 < nkt) stage(kt + 1, slot ^ 1);
+#ifdef ME_ATT_STAMPS
+        }
+#endif
+        ATT_PH(1);
+        const char* kb = smem + slot * (2 * TILE_BYTES);
+        const char* vb = kb + TILE_BYTES;
+        slot ^= 1;
+
+        if (active) {
+            // ---- S' = K Qc^T - m' for the two 32-key halves of the tile
+            f32x16 s[2];
+#ifdef ME_ATT_STAMPS
+            if (abl & 8) {
+                s[0] = negm, s[1] = negm;
+                asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+            } else
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const frag kf = *reinterpret_cast<const frag*>(
+                        kb + ks * 32 * 128 + k_rd + (((2 * st + h) ^ k_swz) << 4));
+                    s[ks] = Mfma32<T>::run(kf, qf[st], st == 0 ? negm : s[ks]);
+                }
+            }
+#ifdef ME_ATT_STAMPS
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+#endif
+            ATT_PH(2);
+            // ---- does the running maximum grow?
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    if (TAIL) {
+                        const int key = kt * KT + ks * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                        if (key >= tokens) s[ks][g] = -INFINITY;
+                    }
+                    mloc = fmaxf(mloc, s[ks][g]);
+                }
+            {
+                // the other lane half holds the other 32 keys of the tile: after the swap `a` is the low half's
+                // maximum in both halves and `b` the high half's.  (As asm: given one value for both operands of
+                // __builtin_amdgcn_permlane32_swap the compiler folds the two results into one and the high half's
+                // keys never reach the comparison.)
+                float a = mloc, b = mloc;
+                // (two wait states between the VALU write of an operand and the swap: the hazard pass cannot see into asm)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+                mloc = fmaxf(a, b);
+            }
+            // The reference point follows the maximum only when some lane's scores pass it by more than defer_thr
+            // (exp2 units; cdna_hip_programming.md T13): until then p = exp2(S') may reach 2^defer_thr instead of 1 --
+            // the same relative precision in the 16-bit P operand, and O and l carry the same factor, so the quotient is
+            // unchanged.  With 32 queries to a wave SOME maximum grows in nearly every tile (the branch, 60 vector
+            // instructions, would run every time); past the threshold almost never after the first tile.
+            if (FIRST || __any(mloc > defer_thr)) {
+                const float delta = FIRST ? mloc : fmaxf(mloc, 0.f);
+                if (!FIRST) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) o[0][g] *= alpha, o[1][g] *= alpha, lsum[g] *= alpha;
+                }
+                m_run += delta;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) s[0][g] -= delta, s[1][g] -= delta, negm[g] = -m_run;
+            }
+            ATT_PH(3);
+            // ---- p = exp2(S')  (raw v_exp_f32: the argument is <= 0, results below 2^-126 may flush to 0)
+#ifdef ME_ATT_STAMPS
+            if (!(abl & 2))
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) s[ks][g] = __builtin_amdgcn_exp2f(s[ks][g]);
+
+#ifdef ME_ATT_STAMPS
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+#endif
+            ATT_PH(4);
+            // ---- O^T += V^T P^T,  l += 1^T P^T
+#ifdef ME_ATT_STAMPS
+            if (abl & 4) {
+                asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+            } else
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    frag pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)s[ks][8 * s2 + j];
+                    lsum = Mfma32<T>::run(ones, pf, lsum);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        s16x4 half0, half1;
+                        {
+                            const int row = ks * 32 + 16 * s2 + 4 * h + v_qrow;
+                            const int chunk = (d * 4 + 2 * v_dhalf + (v_p >> 1)) ^ (((row >> 1) & 1) << 2);
+                            half0 = lds_read_tr16(vb + row * 128 + (chunk << 4) + ((v_p & 1) << 3));
+                        }
+                        {
+                            const int row = ks * 32 + 16 * s2 + 8 + 4 * h + v_qrow;
+                            const int chunk = (d * 4 + 2 * v_dhalf + (v_p >> 1)) ^ (((row >> 1) & 1) << 2);
+                            half1 = lds_read_tr16(vb + row * 128 + (chunk << 4) + ((v_p & 1) << 3));
+                        }
+                        typedef short s16x8 __attribute__((__vector_size__(16)));
+                        const s16x8 both = __builtin_shufflevector(half0, half1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, both), pf, o[d]);
+                    }
+                }
+        }  // active
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the
+                                                             // barrier that lets its slot be restaged
+#ifdef ME_ATT_STAMPS
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(lsum));
+#endif
+        ATT_PH(5);
+    };
+    float l_tot;
+    const bool tail_key = (tokens % KT) == 1 && nkt >= 2;
+    const int nfull = tail_key ? nkt - 1 : nkt;  // tiles that run on the matrix pipe
+    if (nfull == 1) {
+        tile(0, std::true_type(), std::true_type());
+    } else {
+        tile(0, std::true_type(), std::false_type());
+        for (int kt = 1; kt + 1 < nfull; ++kt) tile(kt, std::false_type(), std::false_type());
+        if (tail_key)
+            tile(nfull - 1, std::false_type(), std::false_type());  // a whole tile: 64 valid keys
+        else
+            tile(nfull - 1, std::false_type(), std::true_type());
+    }
+    l_tot = lsum[0];
+    if (tail_key) {
+        // 577 = 9 x 64 + 1: the single key of the last tile (row 0 of the tile staged last) as a rank-one update
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (active) {
+            const char* kb = smem + slot * (2 * TILE_BYTES);
+            const char* vb = kb + TILE_BYTES;
+            float dot = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const frag kf = *reinterpret_cast<const frag*>(kb + ((2 * st + h) << 4));  // row 0: no swizzle
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot = __builtin_fmaf((float)kf[j], (float)qf[st][j], dot);
+            }
+            dot += __shfl_xor(dot, 32);
+            const float rel = dot - m_run;
+            const float delta = fmaxf(rel, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            const float p16 = (float)(T)__builtin_amdgcn_exp2f(rel - delta);  // through the operand type like every other key's
+            l_tot = l_tot * alpha + p16;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    typedef T v4 __attribute__((ext_vector_type(4)));
+                    const v4 vv = *reinterpret_cast<const v4*>(vb + ((4 * d + g4) << 4) + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[d][4 * g4 + e] = __builtin_fmaf(p16, (float)vv[e], o[d][4 * g4 + e] * alpha);
+                }
+        }
+    }
+
+    // ---- normalise and store (see the kernel above)
+    auto round16 = [](float x) -> T {
+        asm volatile("" : "+v"(x));
+        return (T)x;
+    };
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (out8) {
+        const int64_t m = row0 + q;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            float v[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                v[e] = (float)round16(o[d][e] * inv);
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const unsigned sb = mx_scale_byte(amax);
+            const float sc = mx_inv_scale(sb);
+            if (q < tokens) {
+                uint8_t* op = out8 + m * C + head * 64 + d * 32 + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<unsigned*>(op + 8 * g4) =
+                        pack_fp8x4(v[4 * g4] * sc, v[4 * g4 + 1] * sc, v[4 * g4 + 2] * sc, v[4 * g4 + 3] * sc);
+                if (h == 0) out8_scale[a_scale_index(m, head * 2 + d, out8_mt)] = (uint8_t)sb;
+            }
+        }
+    } else if (q < tokens) {
+        T* op = out + (row0 + q) * C + head * 64 + 4 * h;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef T v4 __attribute__((ext_vector_type(4)));
+                v4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round16(o[d][4 * g4 + e] * inv);
+                *reinterpret_cast<v4*>(op + d * 32 + 8 * g4) = v;
+            }
+    }
+#ifdef ME_ATT_STAMPS
+    if (g_att_stamps && lane == 0 && bid < 4096) {
+        ph[6] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int i = 0; i < 7; ++i) g_att_stamps[((size_t)bid * 4 + wave) * 8 + i] = ph[i];
+        // [7]: prologue cycles for active waves, 0 for waves without queries (attn_stamps.py keys on > 0)
+        g_att_stamps[((size_t)bid * 4 + wave) * 8 + 7] = active ? (ph[7] ? ph[7] : 1) : 0;
+    }
+#endif
+}
+
 }  // namespace
 
 #ifdef ME_ATT_STAMPS
@@ -398,11 +775,14 @@ extern "C" int32_t me_debug_set_att_stamps(void* dev_ptr) {
     unsigned long long* p = (unsigned long long*)dev_ptr;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }
+extern "C" int32_t me_debug_set_att_mode(int32_t mode) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_att_mode), &mode, sizeof(mode)) == hipSuccess ? 0 : 1;
+}
 #endif
 
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
                       int32_t dtype, hipStream_t stream, const RowSegs* segs_opt, uint8_t* out8,
-                      uint8_t* out8_scale, int64_t out8_mt) {
+                      uint8_t* out8_scale, int64_t out8_mt, bool q_prescaled) {
     const RowSegs segs = segs_opt ? *segs_opt : RowSegs();
     ME_CHECK(windows > 0 && tokens > 0 && heads > 0, ME_ERR_BAD_SHAPE,
              "attention: windows=%d tokens=%d heads=%d", windows, tokens, heads);
@@ -415,6 +795,23 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
     ProfScope prof(stream, "attention_kernel", 4.0 * windows * heads * (double)tokens * tokens * 64, 0.0);
     // scale = 1/sqrt(64) (vit.rs:47), folded with log2(e) so the softmax runs on exp2
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    if (q_prescaled) {
+        // attention2_kernel.  ME_ATT_THR (development): the deferred-maximum threshold in exp2 units; 0 = the
+        // reference point is the exact running maximum (tools/attn_ab.py compares the two)
+        const char* th = getenv("ME_ATT_THR");
+        const float defer_thr = th ? (float)atof(th) : 8.0f;
+        if (dtype == ME_DTYPE_F16)
+            hipLaunchKernelGGL((attention2_kernel<f16, 3>), grid, dim3(256), 0, stream, (const f16*)qkv, (f16*)out, tokens,
+                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);
+        else if (dtype == ME_DTYPE_BF16)
+            hipLaunchKernelGGL((attention2_kernel<bf16, 3>), grid, dim3(256), 0, stream, (const bf16*)qkv, (bf16*)out, tokens,
+                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);
+        else
+            fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
+        ME_HIP(hipGetLastError());
+        return;
+    }
+    // a plain Q: the kernel that scales the scores itself (scaling and rounding Q again would cost a second rounding)
     if (dtype == ME_DTYPE_F16)
         hipLaunchKernelGGL((attention_kernel<f16, 2, 4>), grid, dim3(256), 0, stream, (const f16*)qkv,
                            (f16*)out, tokens, heads, ngroups, scale_log2e, segs, out8, out8_scale, out8_mt);

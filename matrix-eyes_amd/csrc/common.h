@@ -233,6 +233,12 @@ struct GemmParams {
     unsigned* status;
     // tile rows of an XCD's patch in the tile walk (gemm_core.h tile_origin); 0: 8
     int32_t patch_rows;
+    // EPI_STORE, 16-bit output without activation (the qkv linear, vit.rs:58-62): columns n < qcols leave multiplied
+    // by qscale -- Q of the attention kernel arrives scaled by 1/sqrt(head_dim) * log2(e) with ONE rounding, the
+    // product (acc + bias) * qscale rounded to 16 bits, instead of being scaled and rounded again where it is
+    // consumed (attention.hip attention2_kernel).  qcols == 0: off.  A multiple of 64 (whole heads).
+    int32_t qcols;
+    float qscale;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).
@@ -276,7 +282,9 @@ struct RowSegs {
 // out8_mt = 128-row tiles of the operand) instead of 16-bit `out`
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
                       int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr, uint8_t* out8 = nullptr,
-                      uint8_t* out8_scale = nullptr, int64_t out8_mt = 0);
+                      uint8_t* out8_scale = nullptr, int64_t out8_mt = 0, bool q_prescaled = false);
+// 1/sqrt(head_dim) (vit.rs:47) times log2(e): the factor a pre-scaled Q carries (GemmParams::qscale of the qkv launch)
+constexpr float kAttnQScale = 0.125f * 1.44269504088896340736f;
 
 // ---------------------------------------------------------------------------------------
 // Row-wise and layout kernels (elementwise.hip)

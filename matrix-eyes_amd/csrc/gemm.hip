@@ -180,6 +180,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
+    if (p.qcols)
+        ME_CHECK(epi == EPI_STORE && p.qcols % 64 == 0 && p.qcols <= p.N && p.out16 && !p.out32 && p.act == ACT_NONE &&
+                     !p.lo_off16 && !p.hi2_off16,
+                 ME_ERR_BAD_ARG, "gemm: scaled leading columns (qcols = %d) take a plain 16-bit output", p.qcols);
     int cfg = force_cfg >= 0 ? force_cfg : pick_config(p.M, p.N, p.K, p.seg1, p.seg2, amode == A_PLAIN && epi == EPI_RESID_SCALE);
     // 3x3 convolutions big enough for the 256x256 tile take its halo form (gemm_core.h conv_halo_kernel): the 18 x 18
     // halo of a 16 x 16 pixel tile staged once per 64 input channels instead of the pixels once per tap

@@ -533,6 +533,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 lc.bias[0] = *reinterpret_cast<const float4*>(bias + lc.co);
                 if (hi_ok) lc.bias[1] = *reinterpret_cast<const float4*>(bias + lc.co + 4);
             }
+            if constexpr (EPI == EPI_STORE) {
+                // GemmParams::qcols (the qkv linear): this wave's columns are Q columns -- wave-uniform, qcols being a
+                // multiple of 64 >= TN -- and leave scaled: (acc + bias) * qscale as acc * qscale + bias * qscale, the
+                // accumulators multiplied in place (no register lives longer for it; other tiles skip the branch)
+                const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+                    int, n0 + wn * TN < p.qcols ? p.qscale : 1.0f)));
+                if (cs != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) acc[i][j] *= cs;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        lc.bias[h] = make_float4(lc.bias[h].x * cs, lc.bias[h].y * cs, lc.bias[h].z * cs, lc.bias[h].w * cs);
+                }
+            }
             if constexpr (EPI == EPI_RESID_SCALE) {
                 const float* gamma = seg == 0 ? p.gamma : (seg == 1 ? p.gamma_s1 : p.gamma_s2);
                 lc.gamma[0] = *reinterpret_cast<const float4*>(gamma + n);

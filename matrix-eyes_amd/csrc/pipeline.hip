@@ -77,11 +77,12 @@ void set_out16_split(GemmParams& p, int64_t C) { p.ldc16 = 2 * C, p.lo_off16 = (
 // out = act(A[M][K] . W[N][K]^T + bias) as 16-bit and/or f32 rows of stride ldc
 void linear(me_ctx* ctx, const void* A, int64_t M, int K, const void* W, int N, const float* bias,
             void* out16, float* out32, int64_t ldc, int act, hipStream_t s, bool a_split = false,
-            bool out_split = false) {
+            bool out_split = false, int qcols = 0) {
     GemmParams p = base_params();
     const int Kx = a_split ? 2 * K : K;
     p.M = (int)M, p.N = N, p.K = Kx, p.flop_k = K, p.A = A, p.lda = Kx, p.W = W, p.bias = bias;
     p.out16 = out16, p.out32 = out32, p.ldc = ldc, p.act = act;
+    p.qcols = qcols, p.qscale = kAttnQScale;  // the qkv linear: Q leaves scaled for the attention kernel
     if (out_split) set_out16_split(p, N);
     gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
 }
@@ -230,8 +231,8 @@ struct VitRun {
         const VitBlockW& b = v.blocks[i];
         const int C = ctx->C(), T = ctx->T(), heads = ctx->cfg.num_heads;
         layernorm_launch(tok, b.ln1_w, b.ln1_b, xn, nullptr, rows, C, ctx->cfg.ln_eps, ctx->dtype, s);
-        linear(ctx, xn, rows, C, b.qkv_w, 3 * C, b.qkv_b, qkv, nullptr, 3 * C, ACT_NONE, s);
-        attention_launch(qkv, att, W, T, heads, ctx->dtype, s);
+        linear(ctx, xn, rows, C, b.qkv_w, 3 * C, b.qkv_b, qkv, nullptr, 3 * C, ACT_NONE, s, false, false, C);
+        attention_launch(qkv, att, W, T, heads, ctx->dtype, s, nullptr, nullptr, nullptr, 0, true);
         {
             GemmParams p = base_params();
             p.M = (int)rows, p.N = C, p.K = C, p.A = att, p.lda = C, p.W = b.proj_w;
@@ -407,9 +408,10 @@ struct MergedVit {
 
     // one GEMM over all segments (three weight sets): 16-bit output (qkv, fc1) ...
     void gemm_all(const void* A, int K, const void* w0, const void* w1, const void* w2, const float* b0,
-                  const float* b1, const float* b2, int N, void* out16, int act) {
+                  const float* b1, const float* b2, int N, void* out16, int act, int qcols = 0) {
         GemmParams p = base_params();
         p.M = (int)Rtot, p.N = N, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = b0;
+        p.qcols = qcols, p.qscale = kAttnQScale;  // qkv: Q leaves scaled for the attention kernel
         p.flop_rows = (int)real_rows();
         p.out16 = out16, p.ldc = N, p.act = act;
         p.seg1 = (int)seg1, p.seg2 = (int)seg2, p.W_s1 = w1, p.bias_s1 = b1, p.W_s2 = w2, p.bias_s2 = b2;
@@ -465,6 +467,7 @@ struct MergedVit {
         p.W_s2 = w8(b2), p.w_scale_s2 = ws(b2), p.bias_s2 = bias(b2);
         if (which == 0) {
             p.out16 = qkv;
+            p.qcols = ctx->C(), p.qscale = kAttnQScale;
             gemm_fp8_launch(p, EPI_STORE, s);
         } else if (which == 1) {
             p.act = ACT_GELU;
@@ -494,7 +497,7 @@ struct MergedVit {
                 gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
             } else {
                 layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
-                gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE);
+                gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE, C);
             }
             if (p8) {
                 // the attention kernel writes the projection's fp8 operand itself (the bytes a separate
@@ -502,14 +505,14 @@ struct MergedVit {
                 // the test compares the two)
                 static const bool separate = getenv("ME_FP8_ATT_SEPARATE") != nullptr;
                 if (separate || heads % 2) {
-                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs);
+                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
                     quantize_f16_to_fp8_launch(att, att8, att_s, Rtot, C, 0, s);
                 } else {
-                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, att8, att_s, Rtot / 128);
+                    attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, att8, att_s, Rtot / 128, true);
                 }
                 gemm8(att8, att_s, C, C, b0, b1, b2, 3);
             } else {
-                attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs);
+                attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
                 resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
             }
             set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
@@ -536,8 +539,8 @@ struct MergedVit {
         }
         set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
         layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
-        gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE);
-        attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs);
+        gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE, C);
+        attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
         resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
         set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
         layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);

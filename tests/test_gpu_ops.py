@@ -285,6 +285,101 @@ def test_attention(dtype, tokens, windows, heads):
     assert rel_l2(out.float(), ref) < 1.5 * OUT_EPS[dtype]
 
 
+QSCALE = 0.125 * 1.4426950408889634      # common.h kAttnQScale: 1/sqrt(64) * log2(e)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tokens,windows,heads", [(577, 3, 2), (65, 5, 2), (577, 1, 16), (130, 2, 1), (64, 2, 2), (1, 3, 1)])
+def test_attention_prescaled(dtype, tokens, windows, heads):
+    """The form the forward pass runs: Q arrives multiplied by 1/sqrt(64) * log2(e) (the qkv linear's epilogue does
+    that before its one rounding) and the kernel's softmax runs on exp2 with the reference point inside the MFMA
+    accumulator.  Reference: fp64 softmax of the 16-bit operands as given (exp2 of the scaled scores)."""
+    ctx = ctx_for("tiny", dtype)
+    C = heads * 64
+    g = torch.Generator().manual_seed(tokens + 3 * heads)
+    x = torch.randn(windows * tokens, 3 * C, generator=g) * 1.5
+    x[:, :C] *= QSCALE
+    qkv = dev16(x, dtype)
+    out = torch.empty(windows * tokens, C, dtype=TORCH16[dtype], device="cuda")
+    _check(ctx, ctx.lib.me_op_attention_prescaled(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+    ctx.synchronize()
+    xx = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = xx[0], xx[1], xx[2]
+    s = (q @ k.transpose(3, 2)) * math.log(2.0)             # exp2(s) = exp(s ln 2)
+    ref = (torch.softmax(s, dim=3) @ v).transpose(1, 2).reshape(windows * tokens, C)
+    assert max_err_over_max(out.float(), ref) < 2 * OUT_EPS[dtype]
+    assert rel_l2(out.float(), ref) < 1.5 * OUT_EPS[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_running_max_branches(dtype):
+    """The rescale branch of both kernels (cdna_hip_programming.md rule 26: a rare data-dependent branch needs an input
+    that forces it): keys that dominate their query are planted in EVERY 64-key tile with growing scores (8 natural
+    units = 11.5 exp2 units per tile: past the deferred-maximum threshold of 8 every time), so each tile shifts the
+    reference point -- for query 40 and, more gently, for every query correlated with it; one query sees only strongly
+    NEGATIVE scores (the first tile must set the reference point below zero); one query has its maximum in the single
+    tail key of 577 = 9 x 64 + 1.  ME_ATT_THR=0 (exact running maximum) must agree with the shipped threshold."""
+    ctx = ctx_for("tiny", dtype)
+    tokens, heads, C = 577, 1, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(tokens, 3 * C, generator=g)
+    qi = 40
+    for t in range(9):                                   # key 64 t + 5 scores (t + 2) * 8 against query 40
+        x[64 * t + 5, C:2 * C] = x[qi, 0:C] * (t + 2) * 64.0 / float(x[qi, 0:C].pow(2).sum())
+    x[576, C:2 * C] = x[200, 0:C] * 5.0                  # query 200 attends to the tail key
+    u = torch.full((C,), 0.125)                          # a unit vector: every key gets 4 u (a constant per query) ...
+    x[:, C:2 * C] += 4.0 * u
+    x[100, 0:C] = -175.0 * u                             # ... and query 100 scores every key at -87 +- 22 (natural units)
+    qkv = dev16(x, dtype)
+    for fn in ("me_op_attention", "me_op_attention_prescaled"):
+        xin = qkv.clone()
+        if fn.endswith("prescaled"):
+            xin[:, :C] = (xin[:, :C].float() * QSCALE).to(xin.dtype)
+        out = torch.empty(tokens, C, dtype=TORCH16[dtype], device="cuda")
+        _check(ctx, getattr(ctx.lib, fn)(ctx.handle, ptr(xin), ptr(out), 1, tokens, heads))
+        ctx.synchronize()
+        xx = xin.double()
+        q, k, v = xx[:, :C], xx[:, C:2 * C], xx[:, 2 * C:]
+        s = q @ k.T * (math.log(2.0) if fn.endswith("prescaled") else 0.125)
+        ref = torch.softmax(s, dim=1) @ v
+        assert bool(torch.isfinite(out.float()).all()), fn
+        assert max_err_over_max(out.float(), ref) < 2 * OUT_EPS[dtype], fn
+        assert float((out[qi].double() - v[64 * 8 + 5]).abs().max()) < 0.03, fn    # the last planted key wins
+        assert float((out[200].double() - v[576]).abs().max()) < 0.03, fn
+        if fn.endswith("prescaled"):
+            import os
+            exact = torch.empty_like(out)
+            os.environ["ME_ATT_THR"] = "0"
+            try:
+                _check(ctx, getattr(ctx.lib, fn)(ctx.handle, ptr(xin), ptr(exact), 1, tokens, heads))
+                ctx.synchronize()
+            finally:
+                del os.environ["ME_ATT_THR"]
+            assert max_err_over_max(out.float(), exact.double()) < 2 * OUT_EPS[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,cfg", [(705, 128, -1), (2308, 1024, -1), (2308, 1024, 10), (1024, 256, 0)])
+def test_linear_scaled_cols(dtype, M, C, cfg):
+    """The qkv linear with its Q columns scaled in the epilogue: out16 = round16((A W^T + bias) * qscale) for the first C
+    columns, round16(A W^T + bias) for the rest -- against fp64, and the unscaled columns bit for bit me_op_linear's."""
+    ctx = ctx_for("tiny", dtype)
+    g = torch.Generator().manual_seed(M + C)
+    A = dev16(torch.randn(M, C, generator=g), dtype)
+    W = dev16(torch.randn(3 * C, C, generator=g) / C ** 0.5, dtype)
+    b = (torch.randn(3 * C, generator=g) * 0.5).cuda()
+    got = torch.empty(M, 3 * C, dtype=TORCH16[dtype], device="cuda")
+    plain = torch.empty_like(got)
+    _check(ctx, ctx.lib.me_op_linear_scaled_cols(ctx.handle, M, 3 * C, C, ptr(A), ptr(W), ptr(b), ptr(got), C, QSCALE, cfg))
+    _check(ctx, ctx.lib.me_op_linear(ctx.handle, M, 3 * C, C, ptr(A), ptr(W), ptr(b), ptr(plain), None, 0, cfg))
+    ctx.synchronize()
+    ref = A.double() @ W.double().T + b.double()
+    ref[:, :C] *= QSCALE
+    assert torch.equal(got[:, C:], plain[:, C:])
+    assert max_err_over_max(got.float(), ref) < 1.5 * OUT_EPS[dtype]
+    assert rel_l2(got[:, :C].float(), ref[:, :C]) < OUT_EPS[dtype]
+
+
 def test_attention_token_counts():
     """Every way the sequence can end: one token, one short of / exactly / one past a 64-key tile (the single
     tail key is folded in as a rank-one update) and a 128-query block, the model's 577 and a few in between; a

@@ -332,6 +332,54 @@ def test_config4_chain_batch_of_two(tmp_path):
     assert not torch.equal(stereo[0], stereo[1])
 
 
+def test_config4_chain_batch_of_eight(tmp_path):
+    """BASELINE configs[4] at its per-GPU batch: EIGHT images per step (64 images over 8 GPUs) through depth ->
+    DepthMap::new -> stereogram -> textured OBJ from the model's batched output tensor, the eight OBJ files written
+    behind the caller as bench.py --chain runs it (two pinned buffers, flushed at the end).  Images 1 and 6 of the batch
+    are held to the C oracle: clamp + range and stereogram bit-exact, OBJ + MTL byte-identical to the oracle's writer;
+    their depth is bit for bit that of a batch of one; the eight files differ from one another."""
+    import filecmp
+    import torch
+    from matrix_eyes_amd.synthetic import synthetic_images
+    from util import loaded_ctx
+    ctx = loaded_ctx("full", "f16")
+    S, B = ctx.cfg.img_size, 8
+    rgb = torch.from_numpy(synthetic_images(B, S, "structured", seed=211)).cuda()
+    depth = torch.empty(B, S, S, dtype=torch.float32, device="cuda")
+    ctx.extract_depth(rgb, None, out=depth)
+    ctx.synchronize()
+    checked = (1, 6)
+    raw = {b: depth[b].cpu().numpy().copy() for b in checked}
+    for b in checked:
+        one = ctx.extract_depth(rgb[b:b + 1].cpu().numpy(), None)
+        assert np.array_equal(one[0], raw[b])
+    noise = np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)
+    noise_dev = torch.from_numpy(noise).cuda()
+    ctx.set_write_behind(2)
+    try:
+        maps = [m.DeviceDepthMap(ctx, depth[b], (S, S)) for b in range(B)]
+        stereo = [maps[b].stereogram(1.0 / 16.0, noise_dev) for b in range(B)]
+        for b in range(B):
+            maps[b].output_mesh(str(tmp_path / f"mesh{b}.obj"), f"photo{b}.jpg", m.VertexMode.Texture)
+        ctx.output_flush()
+    finally:
+        ctx.set_write_behind(0)
+    for b in checked:
+        od, mn, mx = OO.clamp_minmax(raw[b])
+        assert maps[b].inverse_depth_range() == (mn, mx) and np.array_equal(depth[b].cpu().numpy(), od)
+        assert np.array_equal(stereo[b].cpu().numpy(), OO.stereogram(od, mn, mx, S, S, 1.0 / 16.0, noise))
+        vi, nv, faces = OO.mesh_index(od)
+        uv, xyz = OO.mesh_vertices(od, vi, nv, (S, S))
+        OO.write_obj(str(tmp_path / f"oracle{b}.obj"), uv, xyz, faces, "texture", f"mesh{b}")
+        assert filecmp.cmp(tmp_path / f"mesh{b}.obj", tmp_path / f"oracle{b}.obj", shallow=False)
+        assert (tmp_path / f"mesh{b}.mtl").read_text() == OO.mtl_text(f"photo{b}.jpg")
+    sizes = [(tmp_path / f"mesh{b}.obj").stat().st_size for b in range(B)]
+    assert min(sizes) > 10e6 and len(set(sizes)) == B
+    assert len({stereo[b].cpu().numpy().tobytes() for b in range(B)}) == B
+    for b in range(B):
+        (tmp_path / f"mesh{b}.obj").unlink()               # 0.6 - 1.3 GB of text on the test box's tmpfs
+
+
 def test_device_number_formatter_prints_like_rust():
     """obj_format.hip's digit generator on the GPU (64 x 128-bit multiplications by __umul64hi, tables in device
     memory) against the oracle's rust_display_f64 (the shortest round-trip digits of CPython's repr laid out positionally): random
