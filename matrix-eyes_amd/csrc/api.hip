@@ -161,6 +161,9 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         ME_HIP(hipSetDevice(device_id));
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
+        ME_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        ME_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ME_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         ME_HIP(hipMalloc((void**)&ctx->status_dev, 256));
         ME_HIP(hipMemset(ctx->status_dev, 0, 256));
         build_weight_table(ctx);
@@ -183,7 +186,10 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     ctx->drop_graph();
+    // the status word of this context may be the calling thread's current one (ME_API_BEGIN): not after this
+    if (me::current_status_word() == ctx->status_dev) me::set_current_status_word(nullptr);
     for (auto& kv : ctx->bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -192,6 +198,9 @@ void me_ctx_destroy(me_ctx* ctx) {
     (void)me_output_flush(ctx);  // pending write-behind files are completed before their buffers go
     for (me_ctx::WriteSlot& w : ctx->write_slots)
         if (w.pinned) (void)hipHostFree(w.pinned);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -479,17 +488,51 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     // the range between decoder and head.
     const float depth_end = f_norm ? 1.0f : 0.8f;
     const float enc_end = 0.8f * depth_end, dec_end = enc_end + 0.98f * (depth_end - enc_end);
-    {
-        ProgressRange r(ctx, 0.05f * enc_end, enc_end);
-        stage_encoder(ctx, img_dev, batch, f_norm == nullptr);
-    }
-    {
-        ProgressRange r(ctx, enc_end + 0.05f * (dec_end - enc_end), dec_end);
-        stage_decoder(ctx, batch, false);
-    }
     const float head_lo = f_norm ? dec_end : 0.99f;
-    float* fnorm_dev = (float*)site_buf(ctx, "f_norm", (size_t)batch * 4);
+    // Side branch (model.h me_ctx::side_stream).  The decoder's levels 4 - 2 and the FOV tail are 40 launches of 15 - 130 us
+    // on 144 - 576 workgroups each -- latency-bound, most of the chip idle -- and depend only on encodings 2 - 4; the
+    // encoder's two latent chains (encodings 1 and 0, read by levels 1 and 0 only) are ConvTranspose launches bound by
+    // their HBM writes.  The two run side by side: fork behind the encoder trunk, join in front of level 1; the
+    // persistent launches of the main branch leave 64 CUs to the side branch meanwhile.  Same kernels, same order per
+    // buffer: the depth is bit for bit that of the one-stream order.
+    static const bool overlap_env = !(getenv("ME_OVERLAP_TAIL") && atoi(getenv("ME_OVERLAP_TAIL")) == 0);
+    const bool overlap = overlap_env && ctx->overlap_tail && ctx->side_stream && !ctx->progress && !profiler().enabled;
     OutBuf ofov;
+    if (overlap) {
+        stage_encoder_trunk(ctx, img_dev, batch, f_norm == nullptr);
+        // every buffer of both branches exists before the fork (an allocation synchronises the stream it is made on)
+        hipStream_t main_stream = ctx->stream;
+        struct Restore {
+            me_ctx* c;
+            hipStream_t s;
+            ~Restore() { c->stream = s, c->grid_cap = 0; }
+        } restore{ctx, main_stream};
+        if (!f_norm) ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
+        ME_HIP(hipEventRecord(ctx->ev_fork, main_stream));
+        ME_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->side_stream;
+        stage_decoder_levels(ctx, batch, false, 4, 4);
+        if (!f_norm) stage_fov_tail(ctx, batch, (float*)ofov.dev);   // needs level 4's lowres features only
+        stage_decoder_levels(ctx, batch, false, 3, 2);
+        ME_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+        ctx->stream = main_stream;
+        static const int cap = getenv("ME_OVERLAP_CAP") ? atoi(getenv("ME_OVERLAP_CAP")) : 192;
+        ctx->grid_cap = cap;
+        stage_encoder_latents(ctx, batch);
+        ctx->grid_cap = 0;
+        ME_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        stage_decoder_levels(ctx, batch, false, 1, 0);
+    } else {
+        {
+            ProgressRange r(ctx, 0.05f * enc_end, enc_end);
+            stage_encoder(ctx, img_dev, batch, f_norm == nullptr);
+        }
+        {
+            ProgressRange r(ctx, enc_end + 0.05f * (dec_end - enc_end), dec_end);
+            stage_decoder(ctx, batch, false);
+        }
+    }
+    float* fnorm_dev = (float*)site_buf(ctx, "f_norm", (size_t)batch * 4);
     if (f_norm) {
         if (is_device_ptr(f_norm))
             ME_HIP(hipMemcpyAsync(fnorm_dev, f_norm, (size_t)batch * 4, hipMemcpyDeviceToDevice,
@@ -497,7 +540,7 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
         else
             ME_HIP(hipMemcpyAsync(fnorm_dev, f_norm, (size_t)batch * 4, hipMemcpyHostToDevice,
                                   ctx->stream));
-    } else {
+    } else if (!overlap) {
         // mod.rs:343-358
         ofov = out_buf(ctx, fov_deg_out ? fov_deg_out : nullptr, (size_t)batch * 4, "fov_deg");
         ProgressRange r(ctx, dec_end, head_lo);

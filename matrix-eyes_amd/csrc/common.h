@@ -239,6 +239,9 @@ struct GemmParams {
     // consumed (attention.hip attention2_kernel).  qcols == 0: off.  A multiple of 64 (whole heads).
     int32_t qcols;
     float qscale;
+    // persistent kernels: at most this many workgroups (a multiple of 8), so that a launch on another stream finds
+    // free CUs beside this one; 0: as many as are resident
+    int32_t grid_cap;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).

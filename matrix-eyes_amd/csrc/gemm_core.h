@@ -1345,6 +1345,7 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
     // the chip instead of the first one taking every CU until it ends
     static const int grid_limit = getenv("ME_GEMM_GRID_LIMIT") ? atoi(getenv("ME_GEMM_GRID_LIMIT")) : 0;
     if (grid_limit >= 8 && grid > grid_limit) grid = grid_limit - grid_limit % 8;
+    if (p.grid_cap >= 8 && grid > p.grid_cap) grid = p.grid_cap - p.grid_cap % 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
     ME_HIP(hipGetLastError());
 }

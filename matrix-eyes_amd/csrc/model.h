@@ -118,6 +118,16 @@ struct me_ctx {
     bool split(int stage_bit) const { return (split_mask & stage_bit) != 0; }
     me_model_config cfg;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // The side branch of extract_depth (api.hip extract_depth_impl): the latency-bound low-resolution decoder levels and
+    // the FOV tail run on `side_stream` beside the bandwidth-bound ConvTranspose chains of the encoder's two latents,
+    // forked and joined by events (captured into the step's hipGraph like any other dependency).  ME_OVERLAP_TAIL=0, a
+    // progress callback or per-kernel timing keep the step on one stream.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_tail = true;
+    // persistent GEMM launches issued while the side branch is in flight leave this many of the 256 CUs to it
+    // (GemmParams::grid_cap); 0: no cap
+    int32_t grid_cap = 0;
     std::string last_error;
     me_progress_fn progress = nullptr;
     void* progress_user = nullptr;
@@ -256,7 +266,13 @@ void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const Vit
 // with_fov: the FOV encoder (fov.rs:57-63 ViT + Linear) runs as a third row segment of the encoder's ViT
 // launches; stage_fov_tail finishes it
 void stage_encoder(me_ctx* ctx, const float* img32, int B, bool with_fov);
+// the two halves of stage_encoder: everything up to encodings 2 - 4 (and the FOV encoder's Linear), then the two
+// latent upsample chains (encodings 0 and 1, encoder.rs:307-309)
+void stage_encoder_trunk(me_ctx* ctx, const float* img32, int B, bool with_fov);
+void stage_encoder_latents(me_ctx* ctx, int B);
 void stage_decoder(me_ctx* ctx, int B, bool want_features32);
+// decoder levels `first` down to `last` (4 = lowest resolution ... 0); stage_decoder = levels 4 to 0
+void stage_decoder_levels(me_ctx* ctx, int B, bool want_features32, int first, int last);
 void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s);
 void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev);
 // f_norm_dev [B]; clamp 0 = canonical (no clamp, f_norm ignored -> 1)

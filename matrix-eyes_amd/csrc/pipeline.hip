@@ -83,6 +83,7 @@ void linear(me_ctx* ctx, const void* A, int64_t M, int K, const void* W, int N, 
     p.M = (int)M, p.N = N, p.K = Kx, p.flop_k = K, p.A = A, p.lda = Kx, p.W = W, p.bias = bias;
     p.out16 = out16, p.out32 = out32, p.ldc = ldc, p.act = act;
     p.qcols = qcols, p.qscale = kAttnQScale;  // the qkv linear: Q leaves scaled for the attention kernel
+    p.grid_cap = ctx->grid_cap;
     if (out_split) set_out16_split(p, N);
     gemm_launch(p, A_PLAIN, EPI_STORE, ctx->dtype, s);
 }
@@ -114,6 +115,7 @@ void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, cons
     p.act = o.act, p.act16_only = o.act16_only ? 1 : 0;
     if (o.split16) set_out16_split(p, Cout);
     if (o.triple16) p.ldc16 = 3 * Cout, p.hi2_off16 = 2 * Cout;
+    p.grid_cap = ctx->grid_cap;
     gemm_launch(p, A_CONV, EPI_STORE, ctx->dtype, s);
 }
 
@@ -138,6 +140,7 @@ void convt(me_ctx* ctx, const void* in16, int B, int H, int W_, int Cin, const v
     } else if (pixel_stride) {
         p.ldc16 = pixel_stride;
     }
+    p.grid_cap = ctx->grid_cap;
     gemm_launch(p, A_PLAIN, EPI_CONVT, ctx->dtype, s);
 }
 
@@ -572,12 +575,37 @@ void vit_forward(me_ctx* ctx, int which, const void* patches16, int W, const Vit
 }
 
 // encoder.rs:218-335 DepthProEncoder::forward_encodings
-void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async /* = with_fov */) {
+void stage_encoder(me_ctx* ctx, const float* img32, int B, bool with_fov) {
+    stage_encoder_trunk(ctx, img32, B, with_fov);
+    stage_encoder_latents(ctx, B);
+}
+
+// encoder.rs:307-309: the two latent upsample chains (taps of blocks 5 and 11 -> encodings 0 and 1).  Nothing but decoder
+// levels 1 and 0 reads their results, and their ConvTranspose launches are bound by HBM writes: extract_depth_impl runs
+// them beside the low-resolution decoder levels (api.hip).
+void stage_encoder_latents(me_ctx* ctx, int B) {
+    hipStream_t s = ctx->stream;
+    const me_model_config& c = ctx->cfg;
+    const int g = ctx->g(), dec = c.dec_dim, e0 = c.enc_dims[0];
+    const bool sp_dec = ctx->split(SPLIT_DEC_CONVS);
+    const size_t wide_dec = sp_dec ? 2 : 1;
+    const int side0 = 4 * g, H0 = 32 * g, H1 = 16 * g;
+    const void* lat0 = ctx->bufs.at("enc.lat0").p;
+    const void* lat1 = ctx->bufs.at("enc.lat1").p;
+    void* enc1 = site_buf(ctx, "enc1.16b", bordered_bytes(B, H1, H1, e0) * wide_dec);
+    run_upsample(ctx, "up_latent1", lat1, B, side0, ctx->w.up_latent1, nullptr, enc1, true, 0,
+                 ACT_NONE, s, sp_dec);
+    float* enc0_32 = (float*)site_buf(ctx, "enc0.f32", (size_t)B * H0 * H0 * dec * 4);
+    void* enc0_r16 = site_buf(ctx, "enc0.r16b", bordered_bytes(B, H0, H0, dec));
+    run_upsample(ctx, "up_latent0", lat0, B, side0, ctx->w.up_latent0, enc0_32, enc0_r16, true, 0,
+                 ACT_RELU, s);
+}
+
+void stage_encoder_trunk(me_ctx* ctx, const float* img32, int B, bool fov_async /* = with_fov */) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), S = ctx->S(), C = ctx->C(), P = ctx->P(), T = ctx->T();
-    const int dec = c.dec_dim, e0 = c.enc_dims[0], e1 = c.enc_dims[1], e2 = c.enc_dims[2],
-              e3 = c.enc_dims[3];
+    const int dec = c.dec_dim, e1 = c.enc_dims[1], e2 = c.enc_dims[2], e3 = c.enc_dims[3];
     const bool sp = ctx->split(SPLIT_UPSAMPLE);  // merged token maps and upsample intermediates as [hi | lo]
     const bool sp_dec = ctx->split(SPLIT_DEC_CONVS);  // encodings 1..4 as [hi | lo] for decoder.convs
     const size_t wide = sp ? 2 : 1, wide_dec = sp_dec ? 2 : 1;
@@ -631,14 +659,7 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async /* = w
 
     report(ctx, 0.7f, "encoding features");
     // encoder.rs:307-316
-    const int H0 = 32 * g, H1 = 16 * g, H2 = 8 * g, H3 = 4 * g, H4 = 2 * g;
-    float* enc0_32 = (float*)site_buf(ctx, "enc0.f32", (size_t)B * H0 * H0 * dec * 4);
-    void* enc0_r16 = site_buf(ctx, "enc0.r16b", bordered_bytes(B, H0, H0, dec));
-    run_upsample(ctx, "up_latent0", lat0, B, side0, ctx->w.up_latent0, enc0_32, enc0_r16, true, 0,
-                 ACT_RELU, s);
-    void* enc1 = site_buf(ctx, "enc1.16b", bordered_bytes(B, H1, H1, e0) * wide_dec);
-    run_upsample(ctx, "up_latent1", lat1, B, side0, ctx->w.up_latent1, nullptr, enc1, true, 0,
-                 ACT_NONE, s, sp_dec);
+    const int H2 = 8 * g, H3 = 4 * g, H4 = 2 * g;   // (encodings 0 and 1: stage_encoder_latents)
     void* enc2 = site_buf(ctx, "enc2.16b", bordered_bytes(B, H2, H2, e1) * wide_dec);
     run_upsample(ctx, "up0", x0f, B, side0, ctx->w.up0, nullptr, enc2, true, 0, ACT_NONE, s, sp_dec);
     void* enc3 = site_buf(ctx, "enc3.16b", bordered_bytes(B, H3, H3, e2) * wide_dec);
@@ -665,7 +686,9 @@ void stage_encoder(me_ctx* ctx, const float* img32, int B, bool fov_async /* = w
 }
 
 // decoder.rs:153-208 MultiresConvDecoder::forward (+ :84-102 FeatureFusionBlock, :35-44 RCU)
-void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
+void stage_decoder(me_ctx* ctx, int B, bool want_features32) { stage_decoder_levels(ctx, B, want_features32, 4, 0); }
+
+void stage_decoder_levels(me_ctx* ctx, int B, bool want_features32, int first, int last) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int g = ctx->g(), dec = c.dec_dim;
@@ -675,8 +698,9 @@ void stage_decoder(me_ctx* ctx, int B, bool want_features32) {
 
     const bool sp_dec = ctx->split(SPLIT_DEC_CONVS), spf = ctx->split(SPLIT_FUSION_OUT),
                sp_head = ctx->split(SPLIT_HEAD);
-    float* feat32 = nullptr;  // `features` carried between levels (f32 residual path)
-    for (int i = 4; i >= 0; --i) {
+    // `features` carried between levels (f32 residual path): the level above left them in its ".feat.f32" buffer
+    float* feat32 = first == 4 ? nullptr : (float*)ctx->bufs.at("dec" + std::to_string(first + 1) + ".feat.f32").p;
+    for (int i = first; i >= last; --i) {
         report(ctx, (4 - i) / 5.0f, i == 4 ? "decoding initial block" : "decoding blocks");
         const std::string L = "dec" + std::to_string(i);
         const int h = H[i];

@@ -394,8 +394,9 @@ def test_extract_depth_full_size_pairs(family, img_seed, ckpt_seed, full_oracle)
         structured/4321, ckpt 2024: rel-L2 7.11e-4, median 1.40e-4, p99 2.29e-2, max 0.45, FOV 54.90174 vs 54.90181
         noise/1234,      ckpt 2024: rel-L2 6.86e-4, median 0.94e-4, p99 2.21e-2, max 0.51, FOV 54.75515 vs 54.75537
         structured/77,   ckpt 7:    rel-L2 5.15e-4, median 3.31e-4, p99 1.19e-2, max 0.074, FOV 54.86040 vs 54.86039
-    The per-pixel tail sits next to the ReLU's zero crossing, where a 2^-11 operand rounding decides between 0 and a
-    small positive value; it is bounded, not 1e-3."""
+    The per-pixel tail is NOT a ReLU-crossing effect (round 3's reading): the error is additive, the same absolute
+    distribution at every reference value, so the relative figure is large exactly where the reference is small against
+    the map's rms -- see the assertions at the end."""
     from matrix_eyes_amd.synthetic import synthetic_checkpoint
     cfg = m.ModelConfig()
     if (family, img_seed, ckpt_seed) == FULL_PAIRS[0]:
@@ -423,6 +424,16 @@ def test_extract_depth_full_size_pairs(family, img_seed, ckpt_seed, full_oracle)
     assert rep["p99"] < 4.0e-2
     assert rep["max"] < 1.0
     assert abs(float(fov[0]) - ref_fov) < 0.01
+    # What the per-pixel tail is (tools/tail_probe.py, profiles/r04_tail_probe.json): the error is
+    # ADDITIVE -- |d - ref| has the same distribution in every band of the reference value (p99 0.011 median(ref) from the
+    # darkest band to the brightest) -- a noise floor that the 2^-11 operand roundings upstream of the head leave in
+    # proportion to the map's own scale.  So it is bounded against rms(ref) for EVERY pixel, and a relative error above
+    # 1e-2 can only occur where the reference value is small against that scale.  Measured (three pairs): max 5.8e-3 /
+    # 5.3e-3 / 3.2e-3 of the rms, p99 2.3e-3 / 2.3e-3 / 1.5e-3, median 1.5e-4 / 1.0e-4 / 2.8e-4; the brightest tail pixel
+    # at 0.45 / 0.42 / 0.24 rms; worst relative error among the pixels at or above the rms 6.1e-3 / 9.0e-3 / 1.2e-3.
+    assert rep["abs_over_rms_max"] < 8.0e-3 and rep["abs_over_rms_p99"] < 3.2e-3 and rep["abs_over_rms_median"] < 4.0e-4
+    assert rep["tail_ref_over_rms_max"] < 0.8                # = abs_over_rms_max / 1e-2: no tail pixel above 0.8 rms
+    assert rep["bright_rel_max"] < 1.0e-2 and rep["bright_fraction"] > 0.02
 
 
 # Burn 0.21's LayerNorm eps and bilinear convention are ASSUMED (1e-5, align_corners = true); the other

@@ -101,14 +101,31 @@ def bordered(x_nchw: torch.Tensor, dtype: str) -> torch.Tensor:
 def depth_error_report(d, ref):
     """Error figures of an inverse-depth map against the oracle's (both [B,S,S] f32 arrays).
     rel = |d - ref| / max(|ref|, 0.05 * median(ref)): relative error with a floor so that the pixels
-    the closing ReLU zeroes (clamped to 1e-4 on both sides) do not divide by ~0."""
+    the closing ReLU zeroes (clamped to 1e-4 on both sides) do not divide by ~0.
+    The per-pixel tail (tools/tail_probe.py): the error is ADDITIVE -- |d - ref| has the same distribution in every
+    band of the reference value (16-bit operand roundings upstream of the head leave a noise floor proportional to the
+    map's own scale, not to the pixel's value) -- so it is measured against the map's rms (abs_*), and the pixels whose
+    RELATIVE error is large are the ones whose reference value is small against that scale (tail_*)."""
     d = np.asarray(d, np.float64)
     ref = np.asarray(ref, np.float64)
-    floor = 0.05 * np.median(ref)
-    rel = np.abs(d - ref) / np.maximum(np.abs(ref), floor)
+    med = float(np.median(ref))
+    floor = 0.05 * med
+    err = np.abs(d - ref)
+    rel = err / np.maximum(np.abs(ref), floor)
+    rms = float(np.sqrt(np.mean(ref * ref)))
+    bad = rel > 1e-2
+    bright = ref >= rms
     return {
         "rel_l2": float(np.linalg.norm(d - ref) / np.linalg.norm(ref)),
         "median": float(np.median(rel)),
         "p99": float(np.quantile(rel, 0.99)),
         "max": float(rel.max()),
+        "rms_over_median": rms / med,
+        "abs_over_rms_median": float(np.median(err) / rms),
+        "abs_over_rms_p99": float(np.quantile(err, 0.99) / rms),
+        "abs_over_rms_max": float(err.max() / rms),
+        "tail_fraction": float(bad.mean()),                                      # pixels with rel > 1e-2
+        "tail_ref_over_rms_max": float(ref[bad].max() / rms) if bad.any() else 0.0,
+        "bright_fraction": float(bright.mean()),                                 # pixels with ref >= rms(ref)
+        "bright_rel_max": float(rel[bright].max()) if bright.any() else 0.0,
     }
