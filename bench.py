@@ -96,36 +96,72 @@ def parse_args():
     return ap.parse_args()
 
 
-def launch_ranks(args):
+def launch_ranks(args, child_cmd=None, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: N child processes, one per GPU, over RCCL.  This process has
     not imported torch or touched the GPU (a process that has must never be replaced or forked from); the children
     are plain `python bench.py ...` commands with the rank environment torch.distributed.run would give them.  Rank
-    0 prints the JSON line on this process's stdout; a rank that fails ends the others."""
+    0 prints the JSON line on this process's stdout, the other ranks' output goes to stderr; a rank that fails ends
+    the others, and so do an interrupt of this process and `timeout_s` (ME_BENCH_RANK_TIMEOUT, default 1800 s: a rank
+    hung in a collective would otherwise hold its GPU for ever).  Returns the worst exit code.
+    child_cmd: the command of a rank (tests pass a stub); default this script with this process's arguments."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("ME_BENCH_RANK_TIMEOUT", "1800"))
+    cmd = child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    # the rendezvous port stays bound (SO_REUSEADDR) until every child exists, so that nothing else takes it in between
+    sock = socket.socket()
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
     worst = 0
-    pending = set(range(args.gpus))
-    while pending:
-        for r in sorted(pending):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            pending.discard(r)
-            if rc != 0:
-                worst = worst or rc
-                for o in pending:              # the others would wait for this rank in a collective for ever
-                    procs[o].terminate()
-        time.sleep(0.05)
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+            procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+        sock.close()
+        sock = None
+        deadline = time.time() + timeout_s
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    for o in pending:              # the others would wait for this rank in a collective for ever
+                        procs[o].terminate()
+            if pending and time.time() > deadline:
+                print(f"bench.py: ranks {sorted(pending)} still running after {timeout_s:.0f} s: ending them", file=sys.stderr)
+                worst = worst or 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        worst = worst or 130
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
+        if sock is not None:
+            sock.close()
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        for p in alive:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     return worst
 
 
@@ -343,6 +379,7 @@ def main():
         per_rank_ms = [None] * world
         dist.all_gather_object(per_rank_ms, my_step_ms)
     assert bool(torch.isfinite(depth).all()), "non-finite depth"
+    # device-result calls leave the flag alone (matrix_eyes_hip.h): this covers every warm-up and timed step
     assert ctx.status_flags() == 0, "an f16 operand overflowed during the benchmark (me_status_flags)"
 
     if rank == 0:

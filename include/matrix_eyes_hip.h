@@ -133,9 +133,10 @@ int32_t me_ctx_synchronize(me_ctx* ctx);
    The reference computes in f32 (decoder.rs:35-44: relu, conv, adds in f32); this back end rounds MFMA operands to
    16 bit.  An f16 operand holds magnitudes up to 65504: past it the operand is +-inf, and behind a conv + ReLU the
    branch drops out silently.  Every kernel that writes 16-bit operands therefore raises ME_STATUS_OVERFLOW_16BIT
-   when that happens.  me_extract_depth[_u8] clears the flag when it starts and, when its result goes to HOST
-   memory, fails with ME_ERR_OVERFLOW itself; with a device result the call is asynchronous and the caller asks
-   here.  bf16 operands (ME_DTYPE_BF16) have f32's range and never raise it. */
+   when that happens.  me_extract_depth[_u8] with a result in HOST memory clears the flag when it starts and fails
+   with ME_ERR_OVERFLOW itself; with a DEVICE result the call is asynchronous and never touches the flag: it stays
+   raised over any number of calls (and graph replays) until the caller asks here.  bf16 operands (ME_DTYPE_BF16)
+   have f32's range and never raise it. */
 int32_t me_status_flags(me_ctx* ctx, uint32_t* flags);
 
 /* ---- weights: mod.rs:174-249 load_record ---------------------------------------------
@@ -297,9 +298,10 @@ int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t h
 /* Write-behind for me_output_mesh(".obj") (BASELINE configs[4]: a batch of images, each ending in a file of 70 - 450 MB).
    files_in_flight >= 2: the call returns once the text sits in pinned host memory; a host thread writes the file (and
    the .mtl) while the caller goes on to the next image.  That many pinned buffers are used in turn, so that many files
-   can be in flight; the next call waits for the oldest (1 is taken as 2).  A failed write is reported (ME_ERR_IO,
-   me_last_error) by the call that next waits for it: a later me_output_mesh, me_ctx_set_write_behind, or
-   me_output_flush, which waits for every pending file.  me_ctx_destroy flushes.  0 (the default): the reference's
+   can be in flight; the next call waits for the oldest (1 is taken as 2) -- and for any pending write to its own
+   destination path -- before it starts any work of its own.  A failed write is reported (ME_ERR_IO, me_last_error) by
+   the call that next waits for it: a later me_output_mesh (which then has written nothing and can be repeated),
+   me_ctx_set_write_behind, or me_output_flush, which waits for every pending file.  me_ctx_destroy flushes.  0 (the default): the reference's
    form, output_mesh returns with the file written. */
 int32_t me_ctx_set_write_behind(me_ctx* ctx, int32_t files_in_flight);
 int32_t me_output_flush(me_ctx* ctx);

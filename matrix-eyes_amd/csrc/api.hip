@@ -574,7 +574,10 @@ void fail_on_overflow(me_ctx* ctx) {
 void enqueue_step(me_ctx* ctx, int entry, const void* in_dev, int32_t batch, const float* f_norm,
                   float* inverse_depth, float* fov_deg_out) {
     const int S = ctx->S();
-    ME_HIP(hipMemsetAsync(ctx->status_dev, 0, 4, ctx->stream));  // the flag describes this call
+    // A call whose result goes to the host reports an overflow itself (fail_on_overflow), so its flag describes this
+    // call alone.  With a device result the flag is STICKY: only me_status_flags reads and clears it, so that a loop of
+    // asynchronous calls (bench.py, a captured graph's replays) cannot lose the overflow of an earlier step.
+    if (!is_device_ptr(inverse_depth)) ME_HIP(hipMemsetAsync(ctx->status_dev, 0, 4, ctx->stream));
     const float* img_dev = (const float*)in_dev;
     if (entry == 1) {
         float* img = (float*)site_buf(ctx, "io.img", (size_t)batch * S * S * 3 * 4);

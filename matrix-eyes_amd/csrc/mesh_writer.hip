@@ -373,6 +373,14 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                  destination_path);
         const bool with_color = vertex_mode == ME_VERTEX_COLOR && vertex_colors;
         const auto t_entry = std::chrono::steady_clock::now();
+        if (ctx->write_behind && obj) {
+            // Before any GPU work of this call: the pinned buffer it will use must be free, and a failed earlier write
+            // is reported NOW (this call has produced nothing yet; the caller can repeat it).  A pending write to the
+            // same destination is waited for as well -- a second fopen("wb") would truncate the file under it.
+            join_pending_write(ctx, ctx->write_next);
+            for (int k = 0; k < (int)ctx->write_slots.size(); ++k)
+                if (ctx->write_slots[(size_t)k].active && ctx->write_slots[(size_t)k].dest == dest) join_pending_write(ctx, k);
+        }
 
         // ---- GPU: IndexedMesh::new + remap_face + vertex coordinates
         const size_t nv = (size_t)width * height;
@@ -406,7 +414,7 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
                 const std::string src(source_path);
                 const size_t nbytes = (size_t)t.bytes;
                 const bool tex = vertex_mode == ME_VERTEX_TEXTURE;
-                w.active = true, w.code = 0, w.msg.clear();
+                w.active = true, w.code = 0, w.msg.clear(), w.dest = dest;
                 w.th = std::thread([&w, dest, stem, src, host, nbytes, tex]() {
                     try {
                         write_file_parallel(dest, host, nbytes);

@@ -164,6 +164,7 @@ struct me_ctx {
         bool active = false;
         int32_t code = 0;
         std::string msg;
+        std::string dest;  // the file the pending write goes to
     };
     std::vector<WriteSlot> write_slots = std::vector<WriteSlot>(1);
     int write_next = 0;

@@ -1,0 +1,87 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torch.distributed.run) on the CPU, with stub
+children: a rank that fails ends the others and its code is returned, nobody is left behind, a hung rank is timed out,
+every child gets the rank environment torch.distributed.run would give it."""
+import os
+import subprocess
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (imports neither torch nor the library at module level)
+
+STUB = r"""
+import os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+open(os.path.join(sys.argv[1], f"pid{rank}"), "w").write(str(os.getpid()))
+mode = sys.argv[2]
+if mode == "ok":
+    print(f"rank {rank} of {world}")
+    sys.exit(0)
+if mode == "rank1_fails":
+    if rank == 1:
+        time.sleep(0.3)
+        sys.exit(7)
+    time.sleep(60)          # "waiting in a collective" for the rank that died
+if mode == "hang":
+    time.sleep(60)
+"""
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    # a zombie of ours would have been reaped by launch_ranks' wait(); anything still signalable is alive
+    try:
+        return open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+    except OSError:
+        return False
+
+
+def _run(tmp_path, mode, n=3, timeout_s=None):
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    args = types.SimpleNamespace(gpus=n)
+    t0 = time.time()
+    rc = bench.launch_ranks(args, child_cmd=[sys.executable, str(stub), str(tmp_path), mode], timeout_s=timeout_s)
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(n)]
+    return rc, pids, time.time() - t0
+
+
+def test_all_ranks_succeed(tmp_path):
+    rc, pids, _ = _run(tmp_path, "ok")
+    assert rc == 0 and not any(_alive(p) for p in pids)
+
+
+def test_a_failing_rank_ends_the_others(tmp_path):
+    rc, pids, took = _run(tmp_path, "rank1_fails")
+    assert rc == 7                                   # the failing rank's code, not the terminated ranks' -15
+    assert took < 20 and not any(_alive(p) for p in pids)
+
+
+def test_hung_ranks_are_timed_out(tmp_path):
+    rc, pids, took = _run(tmp_path, "hang", n=2, timeout_s=1.0)
+    assert rc == 124 and took < 20 and not any(_alive(p) for p in pids)
+
+
+def test_interrupting_the_launcher_ends_the_ranks(tmp_path):
+    """SIGTERM to `python bench.py --gpus 2` itself (a driver's timeout): the children go with it."""
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    code = (f"import sys, types; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"sys.exit(bench.launch_ranks(types.SimpleNamespace(gpus=2), child_cmd=[sys.executable, {str(stub)!r}, {str(tmp_path)!r}, 'hang']))")
+    p = subprocess.Popen([sys.executable, "-c", code])
+    deadline = time.time() + 20
+    while time.time() < deadline and not all((tmp_path / f"pid{r}").exists() for r in range(2)):
+        time.sleep(0.05)
+    time.sleep(0.2)
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(2)]
+    p.terminate()
+    assert p.wait(timeout=20) == 130
+    time.sleep(0.2)
+    assert not any(_alive(q) for q in pids)

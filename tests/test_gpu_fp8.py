@@ -314,6 +314,34 @@ def test_fp8_linears_mask_small_model(mask):
     ctx.close()
 
 
+def test_bcast_weights_rebuilds_the_fp8_arena():
+    """on an fp8 context the e4m3 weight copies are DERIVED data -- me_bcast_weights (and
+    me_weights_adopt) must re-quantise them from the 16-bit arena they have just received.  Here the receiving side of
+    a broadcast is played on one GPU: a context loaded with checkpoint A gets checkpoint B's 16-bit arena written under
+    it (its fp8 copies are now stale: the depth is neither A's nor B's), then me_bcast_weights runs with one rank --
+    communicator, layout check, in-place broadcast, rebuild -- and the depth is bit for bit that of a context loaded
+    with B directly."""
+    from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+    cfg = m.ModelConfig(grid=8, embed_dim=256, num_heads=4, depth=4, tap_blocks=(1, 2), enc_dims=(64, 128, 128, 128),
+                        dec_dim=256, head_dims=(32, 1))
+    rgb = synthetic_images(1, cfg.img_size)
+    b_ctx = m.Context(0, "fp8", cfg)
+    b_ctx.load_state_dict(synthetic_checkpoint(cfg, seed=5))
+    want = b_ctx.extract_depth(rgb, None)
+    ctx = m.Context(0, "fp8", cfg)
+    ctx.load_state_dict(synthetic_checkpoint(cfg, seed=6))
+    a_depth = ctx.extract_depth(rgb, None)
+    assert ctx.weight_arena_layout() == b_ctx.weight_arena_layout() != 0
+    ctx.weight_arena_tensor().copy_(b_ctx.weight_arena_tensor())
+    torch.cuda.synchronize()
+    stale = ctx.extract_depth(rgb, None)             # 16-bit weights of B, fp8 linears still A's
+    assert not np.array_equal(stale, want) and not np.array_equal(stale, a_depth)
+    ctx.bcast_weights(ctx.rccl_unique_id(), 0, 1)
+    assert np.array_equal(ctx.extract_depth(rgb, None), want)
+    ctx.close()
+    b_ctx.close()
+
+
 @pytest.mark.parametrize("windows,tokens,heads", [(3, 577, 4), (5, 65, 2), (2, 130, 16), (1, 128, 2)])
 def test_attention_fp8_output_equals_quantised_16bit_output(windows, tokens, heads):
     ctx = ctx_for("tiny", "f16")

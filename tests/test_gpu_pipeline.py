@@ -297,6 +297,15 @@ def test_f16_overflow_is_reported_not_swallowed():
     out = torch.empty(1, cfg.img_size, cfg.img_size, dtype=torch.float32, device="cuda")
     ctx.extract_depth(torch.from_numpy(rgb).cuda(), 1.0, out=out)      # asynchronous: no error here ...
     assert ctx.status_flags() == 1 and ctx.status_flags() == 0          # ... the flag says so, once
+    # the flag is sticky over asynchronous calls: an overflowing step followed by clean steps on ANOTHER
+    # context state would be lost if every step cleared it -- here three device-result calls, one poll
+    for _ in range(3):
+        ctx.extract_depth(torch.from_numpy(rgb).cuda(), 1.0, out=out)
+    good_out = torch.empty_like(out)
+    assert ctx.status_flags() == 1 and ctx.status_flags() == 0
+    good.extract_depth(torch.from_numpy(rgb).cuda(), 1.0, out=good_out)
+    good.extract_depth(torch.from_numpy(rgb).cuda(), 1.0, out=good_out)
+    assert good.status_flags() == 0
     ctx.close()
     bctx = m.Context(0, "bf16", cfg)
     bctx.load_state_dict(w)

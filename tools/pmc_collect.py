@@ -51,12 +51,6 @@ def describe(op, cfg):
         out = rows * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
         bytes_ = rows * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
-    if False:
-        n, k = 0, 0
-        resid = op in ("proj", "fc2")
-        out = PROBE_M * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
-        bytes_ = PROBE_M * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
-        return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
     if op in SHAPES8:
         n, k = SHAPES8[op]
         resid = op == "fc2_8"
@@ -74,12 +68,19 @@ KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_ke
 def run_pass(op, cfg, counters, work):
     out = os.path.join(work, f"{op}_{'_'.join(counters)}"[:80])
     probe, rows = (SHAPES[op][0], SHAPES[op][3]) if op in SHAPES else (op, PROBE_M)
+    # the interpreter itself after `--`, never a launcher script: the profiler's preloaded library has initialised
+    # the GPU by then and this pool forbids an exec hop from such a process
     cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
-           "--", "python3", os.path.join(ROOT, "tools", "gemm_probe.py"), probe, str(cfg), "6"]
+           "--", os.path.realpath(sys.executable), os.path.join(ROOT, "tools", "gemm_probe.py"), probe, str(cfg), "6"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PROBE_M=str(rows)),
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-    if r.returncode != 0:     # e.g. a counter this rocprofv3 build does not list
-        return {}, None
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, text=True)
+    if r.returncode != 0:
+        low = (r.stdout or "").lower()
+        if any(c.lower() in low for c in counters) and ("not found" in low or "unknown" in low or "invalid" in low
+                                                        or "unsupported" in low or "not supported" in low):
+            print(f"pmc_collect: rocprofv3 does not know {counters}: pass skipped", flush=True)
+            return {}, None
+        raise RuntimeError(f"rocprofv3 pass {counters} on {op}:{cfg} failed with code {r.returncode}:\n{(r.stdout or '')[-2000:]}")
     vals, durs = {}, []
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
