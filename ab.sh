@@ -1,12 +1,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4f
-cd /tmp && export TMPDIR=/tmp
-for mode in 0 1; do
-  ME_OVERLAP_TAIL=$mode timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r4f/trace$mode -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r4f/bench_trace$mode.txt 2>&1
-  f=$(find $GRAFT_REPO_ROOT/gpurun_out/r4f/trace$mode -name "*kernel_trace.csv" | head -1)
-  python3 $GRAFT_REPO_ROOT/tools/step_timeline.py $f 2 -v > $GRAFT_REPO_ROOT/gpurun_out/r4f/timeline$mode.txt 2>&1
-  rm -rf $GRAFT_REPO_ROOT/gpurun_out/r4f/trace$mode
-done
-cd $GRAFT_REPO_ROOT
-grep -n "busy per queue\|step of" gpurun_out/r4f/timeline0.txt gpurun_out/r4f/timeline1.txt
+mkdir -p gpurun_out/r4g
+timeout -k 10 120 python tools/ln_debug.py 2>&1 | grep -v amdgpu.ids
+timeout -k 10 600 python -m pytest tests/test_gpu_ops.py -q -x -k "layernorm_fused" > gpurun_out/r4g/pytest_ops.txt 2>&1; echo "ops rc=$?"
+tail -3 gpurun_out/r4g/pytest_ops.txt
+rm -f gpurun_out/r4g/bench_ab.txt
+for rep in 1 2; do
+for v in "ME_LN_FUSE=0" "ME_LN_FUSE=1"; do
+  echo "== $v" >> gpurun_out/r4g/bench_ab.txt
+  env $v timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], [(k['kernel'][:44],k['launches_per_step'],k['ms_per_step']) for k in d['kernels'][:6]])" >> gpurun_out/r4g/bench_ab.txt 2>&1
+done; done
+cat gpurun_out/r4g/bench_ab.txt

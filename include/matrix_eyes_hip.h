@@ -51,7 +51,9 @@ enum {
 
 /* ---- me_status_flags bits ---------------------------------------------------------------- */
 enum {
-    ME_STATUS_OVERFLOW_16BIT = 1 /* a kernel rounded a magnitude beyond 65504 to an f16 operand (stored as +-inf) */
+    ME_STATUS_OVERFLOW_16BIT = 1, /* a kernel rounded a magnitude beyond 65504 to an f16 operand (stored as +-inf) */
+    ME_STATUS_SYNC_TIMEOUT = 2    /* a workgroup gave up waiting for its neighbours' LayerNorm statistics (the fused
+                                     residual epilogue; never seen on a healthy device): the result is not valid */
 };
 
 /* ---- arithmetic type of the MFMA operands (accumulation is always f32) --------------- */

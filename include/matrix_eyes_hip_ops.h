@@ -79,6 +79,14 @@ int32_t me_op_linear_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uin
 int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1, int32_t seg2,
                               const void* const W16[3], const float* const bias[3], const float* const gamma[3],
                               void* out16, float* x32, int32_t act, int32_t tile_cfg);
+/* The residual update of me_op_linear_segments with the LayerNorm of the next sublayer in the same launch (the form
+   the forward pass runs, vit.rs:165-169; csrc/gemm_core.h resid_ln_epilogue): x32[M][N] += gamma * (A W^T + bias) in
+   place and xn16[m][:] = LayerNorm(x32[m][:], eps) * ln_w + ln_b with the weights of the row's segment.  N in {256,
+   512, 1024}; the 352-row tile, whose N / 256 column tiles exchange their partial statistics through memory. */
+int32_t me_op_linear_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
+                                        int32_t seg2, const void* const W16[3], const float* const bias[3],
+                                        const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
+                                        float eps, float* x32, void* xn16);
 /* me_op_linear_fp8 over up to three row segments with their own weights, as the encoder's merged ViT launches run
    it (pipeline.hip MergedVit): rows [0, seg1) use W8[0] / w_scale[0] / bias[0] (/ gamma[0]), [seg1, seg2) the [1]
    set, [seg2, M) the [2] set; seg1, seg2 multiples of 256, seg2 == 0: two segments, seg1 == 0: one. */

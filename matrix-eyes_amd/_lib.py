@@ -10,6 +10,7 @@ ERROR_NAMES = {
     7: "IO", 8: "NOT_READY", 9: "OOM", 10: "OVERFLOW",
 }
 ME_STATUS_OVERFLOW_16BIT = 1
+ME_STATUS_SYNC_TIMEOUT = 2
 ME_DTYPE_F16, ME_DTYPE_BF16, ME_DTYPE_FP8 = 0, 1, 2
 ME_WEIGHT_F32, ME_WEIGHT_F16, ME_WEIGHT_BF16, ME_WEIGHT_F64 = 0, 1, 2, 3
 ME_VIT_PATCH_ENCODER, ME_VIT_IMAGE_ENCODER, ME_VIT_FOV_ENCODER = 0, 1, 2
@@ -102,6 +103,8 @@ SIGNATURES = {
                                          C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _vp]),
     "me_op_linear_segments": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                      _vp, _vp, _i32, _i32]),
+    "me_op_linear_residual_layernorm": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                               C.POINTER(_vp), C.POINTER(_vp), _f32, _vp, _vp]),
     "me_op_format_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),
     "me_op_cast_to32": (_i32, [_vp, _vp, _vp, _i64]),

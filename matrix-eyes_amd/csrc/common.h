@@ -239,6 +239,17 @@ struct GemmParams {
     // consumed (attention.hip attention2_kernel).  qcols == 0: off.  A multiple of 64 (whole heads).
     int32_t qcols;
     float qscale;
+    // LayerNorm of the updated token rows inside EPI_RESID_SCALE (gemm_core.h resid_ln_epilogue; the 352-row tile, N in
+    // {256, 512, 1024}): besides x += gamma * (A W^T + b) the launch writes ln_out16[m][:] = LayerNorm(x[m][:]) * w + b
+    // with the weights of the row's segment -- the next linear's operand (vit.rs:165-169: norm1 / norm2 of Block::forward).
+    // The N / 256 column tiles of a row tile exchange their partial (mean, M2) through ln_stats ([row tile][column tile]
+    // [352] 8-byte granules) and count their arrivals in ln_count (one word per row tile, 64 bytes apart; the count only
+    // ever grows by N / 256 per launch, so it needs no reset between launches or graph replays).  ln_out16 == null: off.
+    void* ln_out16;
+    const float *ln_w, *ln_b, *ln_w_s1, *ln_b_s1, *ln_w_s2, *ln_b_s2;
+    float ln_eps;
+    unsigned long long* ln_stats;
+    unsigned* ln_count;
     // persistent kernels: at most this many workgroups (a multiple of 8), so that a launch on another stream finds
     // free CUs beside this one; 0: as many as are resident
     int32_t grid_cap;

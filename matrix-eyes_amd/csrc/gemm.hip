@@ -180,6 +180,14 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
+    if (p.ln_out16) {
+        ME_CHECK(force_cfg == CFG_PP352 && amode == A_PLAIN && epi == EPI_RESID_SCALE && (p.N == 256 || p.N == 512 || p.N == 1024) &&
+                     p.ldc == p.N && p.ln_w && p.ln_b && p.ln_stats && p.ln_count && p.bias && p.gamma && p.res32 && p.out32 &&
+                     p.K >= 128,
+                 ME_ERR_BAD_ARG, "gemm: the fused LayerNorm takes the 352-row tile's residual epilogue with N in {256, 512, 1024}");
+        ME_CHECK(p.seg1 == 0 || (p.ln_w_s1 && p.ln_b_s1 && (p.seg2 == 0 || (p.ln_w_s2 && p.ln_b_s2))), ME_ERR_BAD_ARG,
+                 "gemm: a row segment without LayerNorm weights");
+    }
     if (p.qcols)
         ME_CHECK(epi == EPI_STORE && p.qcols % 64 == 0 && p.qcols <= p.N && p.out16 && !p.out32 && p.act == ACT_NONE &&
                      !p.lo_off16 && !p.hi2_off16,

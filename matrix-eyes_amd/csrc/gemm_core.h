@@ -244,7 +244,8 @@ __device__ __forceinline__ void seg_tile_rows(const GemmParams& p, int rt, int& 
 // by 8 (with the plain n-fastest order the whole W matrix streams through L2 once per tile row:
 // 44 % L2 misses on the fc1 shape, profiles/r01_pmc_gemm.md).
 template <int BM, int BN, bool SEG = false>
-__device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0, int* m_lim = nullptr) {
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nwg, int& m0, int& n0, int* m_lim = nullptr,
+                                            int* row_tile = nullptr) {
     const int GM = SEG && p.patch_rows ? p.patch_rows : 8;
     const int nbm = SEG ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -255,6 +256,7 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int bid, int nw
     const int h = min(GM, nbm - sr * GM);  // rows of this super-row
     const int n = rem / h;
     const int rr = rem - n * h;
+    if (row_tile) *row_tile = sr * GM + rr;
     if constexpr (SEG) {
         int lim;
         seg_tile_rows<BM>(p, sr * GM + rr, m0, lim);
@@ -740,6 +742,255 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// EPI_RESID_SCALE with the LayerNorm that follows it (GemmParams::ln_out16; vit.rs:165-169: x = x + ls(attn(norm1 x)),
+// x = x + ls(mlp(norm2 x)) -- every residual update is followed by the norm of the next sublayer).  The stand-alone
+// LayerNorm launch re-read the 89 MB token stream the epilogue had just written (21.5 us x 48 per step); here the
+// updated rows are normalised while the workgroup still holds them in registers.
+//
+// A row's statistics need all N columns and a 352-row tile has 256 of them, so the N / 256 column tiles of a row tile
+// -- workgroups that run in the same round of the persistent kernel, on the same XCD by the tile walk, but on other
+// CUs -- exchange partial statistics through memory:
+//   1. as before: x_new = (acc + bias) * gamma + x, stored pass by pass; the values stay in registers (the accumulators
+//      they replace are dead), and each wave reduces (mean, M2) of its 64 columns per row over the 8 lanes that share
+//      a row (two shuffle reductions: the sum, then the squares about the wave's own mean) into LDS;
+//   2. 352 threads combine the four waves' partials per row (Chan's parallel form, fixed order) and publish the tile's
+//      (mean, M2) as ONE 8-byte write-through store per row; every storing wave drains, the workgroup meets, one lane
+//      adds 1 to the row tile's arrival counter (cdna_hip_programming.md Guideline 16, recipe R1);
+//   3. that lane polls the counter until all N / 256 tiles have arrived (the count grows by N / 256 per launch and is
+//      never reset: the target is the next multiple above the value the add returned), the workgroup meets again, and
+//      the 352 threads read ALL column tiles' granules with write-through-coherent loads -- their own included, so
+//      that every column tile combines the same numbers in the same order and a row's statistics do not depend on
+//      which tile computes them -- into (mean, rstd) per row in LDS;
+//   4. the retained values leave as (x - mean) * rstd * w + b, 16 bytes per lane and row.
+// All workgroups of a round are resident (a persistent grid never exceeds what fits), so the wait cannot deadlock; it is
+// bounded all the same and raises ME_STATUS_SYNC_TIMEOUT instead of hanging.  Statistics differ from the stand-alone
+// kernel's in the order of their sums only (1e-7 relative); a row's result does not depend on the batch it is part of.
+template <typename T, int MI, int NI, int TM, int TN, int BM>
+__device__ __forceinline__ void resid_ln_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0, int wm,
+                                                  int wn, int lane, int tid, char* epi_lds, char* shared, int m_lim,
+                                                  int row_tile) {
+    static_assert(TN == 64 && NI == 4 && BM == 2 * TM, "written for the 352 x 256 tile: 2 x 4 waves of 176 x 64");
+    // Every per-lane constant of this epilogue (LDS addresses of the transposition, store offsets, row indices) is derived
+    // from these two HERE, behind an opaque use: derived from the kernel's own `lane` they are loop-invariant, get
+    // hoisted in front of the persistent tile loop, live through the K loop's 256 registers as spills, and come back
+    // as a dozen dependent scratch reloads per tile (3 us) -- 30 integer instructions per tile are cheaper.
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    constexpr int RS = TN * 4, ROWS = 16, GPR = 8, RPI = 8, ITERS = 2, NP = MI, CMASK = 15, WN = 4;
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const int Mrows = m_lim;
+    const int frow = lane & 15, ncol = (lane >> 4) * 4;
+    const int gc = lane % GPR, r0 = lane / GPR;
+    const int n = n0 + wn * TN + gc * 8;  // N is a multiple of 256: every column exists
+    const int seg = row_segment(p, m0);
+    const float* bias = seg == 0 ? p.bias : (seg == 1 ? p.bias_s1 : p.bias_s2);
+    const float* gamma = seg == 0 ? p.gamma : (seg == 1 ? p.gamma_s1 : p.gamma_s2);
+    float4 cb[2], cg[2];
+    cb[0] = *reinterpret_cast<const float4*>(bias + n), cb[1] = *reinterpret_cast<const float4*>(bias + n + 4);
+    cg[0] = *reinterpret_cast<const float4*>(gamma + n), cg[1] = *reinterpret_cast<const float4*>(gamma + n + 4);
+    asm volatile("" : "+v"(cb[0].x), "+v"(cb[0].y), "+v"(cb[0].z), "+v"(cb[0].w), "+v"(cb[1].x), "+v"(cb[1].y), "+v"(cb[1].z), "+v"(cb[1].w));
+    asm volatile("" : "+v"(cg[0].x), "+v"(cg[0].y), "+v"(cg[0].z), "+v"(cg[0].w), "+v"(cg[1].x), "+v"(cg[1].y), "+v"(cg[1].z), "+v"(cg[1].w));
+    const int mw = m0 + wm * TM;
+    const int64_t wave_el = (int64_t)mw * p.ldc + n0 + wn * TN;
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr((const char*)(p.res32 + wave_el))), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr((const char*)(p.out32 + wave_el))), 0, 0x7fffffff, 0x00020000);
+    const unsigned row_step = (unsigned)p.ldc * 4u;
+    const unsigned loff = (unsigned)r0 * row_step + gc * 32u;
+    const int rows_left = Mrows - mw - r0;
+    constexpr unsigned kOut = 0x80000000u;
+    auto voff = [&](int rt) { return rt < rows_left ? loff : kOut; };
+    float2* stw = reinterpret_cast<float2*>(shared);                  // [BM][WN]: a wave's (mean, M2) of 64 columns
+    float2* fin = reinterpret_cast<float2*>(shared + BM * WN * 8);    // [BM]: (mean, rstd) of the whole row
+    // the updated values take the place of the accumulators they were computed from: xs(pass, it, h) = acc[pass][2 it + h]
+    static_assert(NI == 2 * ITERS, "a pass's four accumulator tiles hold its 2 x 2 result vectors");
+#define ME_XS(pass, it, h) acc[pass][2 * (it) + (h)]
+    f32x4 res[ITERS][2];
+    auto load_res = [&](int pass) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rt = pass * ROWS + it * RPI;
+            const unsigned so = (unsigned)rt * row_step;
+            res[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, voff(rt), so, 0));
+            res[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, voff(rt) + 16u, so, 0));
+        }
+    };
+    load_res(0);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            *reinterpret_cast<f32x4*>(epi_lds + frow * RS + ((((j * 16 + ncol) >> 2) ^ frow) & CMASK) * 16) = acc[pass][j];
+        f32x4 xn_[ITERS][2];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rr = it * RPI + r0;
+            const char* src = epi_lds + rr * RS;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((2 * gc + h) ^ rr) & CMASK) * 16);
+                const float4 b4 = cb[h], g4 = cg[h];
+                // same operation order as the reference: (xs * gamma) + residual
+                const f32x4 xnew = f32x4{(v[0] + b4.x) * g4.x + res[it][h][0], (v[1] + b4.y) * g4.y + res[it][h][1],
+                                        (v[2] + b4.z) * g4.z + res[it][h][2], (v[3] + b4.w) * g4.w + res[it][h][3]};
+                xn_[it][h] = xnew;
+            }
+        }
+        // (the pass's accumulators have all gone through LDS by now: their registers take the new values)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) ME_XS(pass, it, 0) = xn_[it][0], ME_XS(pass, it, 1) = xn_[it][1];
+        if (pass + 1 < NP) load_res(pass + 1);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rt = pass * ROWS + it * RPI;
+            const unsigned so = (unsigned)rt * row_step;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ME_XS(pass, it, 0)), rout, voff(rt), so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ME_XS(pass, it, 1)), rout, voff(rt) + 16u, so, 0);
+        }
+    }
+    // ---- this wave's 64-column statistics of its 22 rows per lane: eight lanes share a row.  Reductions over those
+    // eight lanes by DPP (quad_perm for the lane pairs at distance 1 and 2, row_shr:4 to bring the lower quad's sum to
+    // the upper quad, row_shl:4 to hand the total back): vector instructions, no LDS round trip -- as ds_bpermute (what
+    // __shfl_xor compiles to) they were 132 dependent LDS operations per lane inside the pass loop.  Outside the loop
+    // the 22 rows are independent chains.
+    auto dpp_add = [](float v, auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+        return v + __builtin_bit_cast(float, moved);
+    };
+    auto oct_sum = [&](float v) {  // the sum over the 8 lanes of a row, valid in all of them
+        v = dpp_add(v, std::integral_constant<int, 0xB1>());   // quad_perm [1,0,3,2]
+        v = dpp_add(v, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]: every lane of a quad has the quad's sum
+        const float up = dpp_add(v, std::integral_constant<int, 0x114>());  // row_shr:4: lanes 4-7 (12-15) add lanes 0-3 (8-11)
+        const int down = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, up), 0x104, 0xf, 0xf, true);  // row_shl:4
+        return (lane & 4) ? up : __builtin_bit_cast(float, down);
+    };
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const f32x4 a = ME_XS(pass, it, 0), b = ME_XS(pass, it, 1);
+            const float sum = oct_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])));
+            const float mean = sum * (1.0f / 64.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = a[e] - mean, d1 = b[e] - mean;
+                q = __builtin_fmaf(d0, d0, q), q = __builtin_fmaf(d1, d1, q);
+            }
+            q = oct_sum(q);
+            if (gc == 0) stw[(wm * TM + pass * ROWS + it * RPI + r0) * WN + wn] = make_float2(mean, q);
+        }
+    // the LayerNorm weights of this lane's columns: requested now, needed behind the exchange (bias and gamma are done)
+    {
+        const float* lw = seg == 0 ? p.ln_w : (seg == 1 ? p.ln_w_s1 : p.ln_w_s2);
+        const float* lb = seg == 0 ? p.ln_b : (seg == 1 ? p.ln_b_s1 : p.ln_b_s2);
+        cb[0] = *reinterpret_cast<const float4*>(lb + n), cb[1] = *reinterpret_cast<const float4*>(lb + n + 4);
+        cg[0] = *reinterpret_cast<const float4*>(lw + n), cg[1] = *reinterpret_cast<const float4*>(lw + n + 4);
+    }
+    // ---- the tile's statistics per row, published
+    const int nbn = p.N / 256, ct = n0 / 256;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gu64* granules = (gu64*)(p.ln_stats + (size_t)row_tile * nbn * BM);
+    auto chan = [](float& n_a, float& mean_a, float& m2_a, float n_b, float mean_b, float m2_b) {
+        const float nn = n_a + n_b, d = mean_b - mean_a, f = n_b / nn;
+        mean_a = __builtin_fmaf(d, f, mean_a);
+        m2_a = m2_a + m2_b + d * d * (n_a * f);
+        n_a = nn;
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < BM) {
+        const float2 w0 = stw[tid * WN];
+        float cn = 64.f, cm = w0.x, c2 = w0.y;
+#pragma unroll
+        for (int k = 1; k < WN; ++k) {
+            const float2 wk = stw[tid * WN + k];
+            chan(cn, cm, c2, 64.f, wk.x, wk.y);
+        }
+        const unsigned long long g = ((unsigned long long)__builtin_bit_cast(unsigned, c2) << 32) | __builtin_bit_cast(unsigned, cm);
+        __hip_atomic_store(granules + (size_t)ct * BM + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __builtin_amdgcn_s_barrier();                      // ... before ONE lane signals for the workgroup
+    asm volatile("" ::: "memory");
+    if (nbn > 1) {
+        if (tid == 0) {
+            gu32* cnt = (gu32*)(p.ln_count + (size_t)row_tile * 16);
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (old / (unsigned)nbn + 1u) * (unsigned)nbn;
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) {  // seconds: the neighbours are resident and arrive within microseconds
+                    if (p.status) atomicOr(p.status, 2u);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (tid < BM) {
+        float cn = 0.f, cm = 0.f, c2 = 0.f;
+        for (int k = 0; k < nbn; ++k) {  // every column tile, this one included, in the same order everywhere
+            const unsigned long long g = __hip_atomic_load(granules + (size_t)k * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float gm = __builtin_bit_cast(float, (unsigned)g), g2 = __builtin_bit_cast(float, (unsigned)(g >> 32));
+            if (k == 0) cn = 256.f, cm = gm, c2 = g2;
+            else chan(cn, cm, c2, 256.f, gm, g2);
+        }
+        const float var = c2 / cn;
+        fin[tid] = make_float2(cm, 1.0f / sqrtf(var + p.ln_eps));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- the normalised rows
+    const int64_t wave_el16 = (int64_t)mw * p.N + n0 + wn * TN;
+    const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(uniform_ptr((const char*)((T*)p.ln_out16 + wave_el16))), 0, 0x7fffffff, 0x00020000);
+    const unsigned row_step16 = (unsigned)p.N * 2u;
+    const unsigned loff16 = (unsigned)r0 * row_step16 + gc * 16u;
+    float amax16 = 0.f;
+    // the store offset and the rows this lane has left walk with the loop (RPI rows per step) as RUNNING values: left
+    // to itself the compiler computes all 22 offsets up front, spills them, and every step's reload waits -- vmcnt
+    // counts stores -- for every store before it (1.2 us each: the whole 16-bit stream serialised, 26 us per tile)
+    unsigned cur16 = loff16;
+    int left16 = rows_left;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rt = pass * ROWS + it * RPI;
+            asm volatile("" : "+v"(cur16), "+v"(left16));
+            const float2 ms = fin[wm * TM + rt + r0];
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 x = ME_XS(pass, it, h);
+                const float4 w4 = cg[h], b4 = cb[h];
+                o[4 * h + 0] = (x[0] - ms.x) * ms.y * w4.x + b4.x, o[4 * h + 1] = (x[1] - ms.x) * ms.y * w4.y + b4.y;
+                o[4 * h + 2] = (x[2] - ms.x) * ms.y * w4.z + b4.z, o[4 * h + 3] = (x[3] - ms.x) * ms.y * w4.w + b4.w;
+            }
+            track_amax16<T>(amax16, o, true);
+            typedef T v8 __attribute__((ext_vector_type(8)));
+            v8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (T)o[e];
+            // The row offset goes into the VECTOR offset, not the scalar one: the next iteration's conversions rewrite
+            // this store's data registers at once, and with a register in the soffset field the compiler's hazard pass
+            // assumes that a wide store has read its data by then -- on gfx950 it has not (the second dword came out
+            // overwritten for a quarter of the lanes).  With soffset 0 the pass inserts the wait states itself.
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ov), r16, left16 > 0 ? cur16 : kOut, 0, 0);
+            cur16 += (unsigned)RPI * row_step16, left16 -= RPI;
+        }
+    raise_overflow16<T>(p.status, amax16);
+}
+#undef ME_XS
+
 // sched_group_barrier wants literal counts: compile-time recursion over the fragment groups
 template <int G, int NI, int g>
 struct SchedPin {
@@ -997,8 +1248,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
 // (160 KiB for the 256x256 tile: all of a CU's LDS).  One barrier per slab as before; group 1 closes a
 // slab with a counted vmcnt (its newest DMA group may stay in flight), group 0 with vmcnt(0).
 // Requires K >= 128.
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3>
+// LNF: the residual epilogue also writes the LayerNorm of the rows it updates (resid_ln_epilogue above)
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+    static_assert(!LNF || (BM > 256 && EPI == EPI_RESID_SCALE), "LayerNorm fusion: the 352-row tile's residual epilogue");
     static_assert(WSLOTS == 3 || WSLOTS == 2, "weight ring of three slots (two slabs ahead) or two (one ahead)");
     static_assert(WM * WN == 8, "two groups of four waves");
     static_assert(BM / WM >= BN / WN, "the first k-substep's MI groups prefetch the NI weight fragments");
@@ -1030,7 +1283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 
     const int srow = lane >> 3, sslot = lane & 7;
     struct Src {
-        int m0, n0, m_lim;
+        int m0, n0, m_lim, row_tile;
         // this wave's DMA sources, activation rows (group 0) or weight rows (group 1): a uniform base (the
         // tile's first row) and per-lane 32-bit byte offsets from it -- the kernel has no VGPR to spare
         // for 64-bit pointers
@@ -1039,7 +1292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     };
     auto pixel_of = [&](int gm) -> int64_t { return conv_pixel(p, gm); };
     auto setup = [&](Src& t, int vb) {
-        tile_origin<BM, BN, TALL>(p, vb, ntiles, t.m0, t.n0, &t.m_lim);
+        tile_origin<BM, BN, TALL>(p, vb, ntiles, t.m0, t.n0, &t.m_lim, &t.row_tile);
         if constexpr (TALL) {
             // piece i of a lane: row (i * HW + gw) * 8 + srow of the tile, always the same 16-byte chunk position
             // (the swizzle repeats every 16 rows) -- offsets are affine in i; rows beyond the operand's last row
@@ -1288,6 +1541,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         {
             const int wprev = WSLOTS == 2 ? (ws ^ 1) : (ws == 0 ? 2 : ws - 1);
             char* scr = (group == 0 ? scratch0 : smem + W_RING + wprev * B_BYTES) + gw * SCR;
+            if constexpr (LNF) {
+                // the statistics of the tile's rows go through the rest of the activation slot that holds group 0's scratch
+                static_assert(HW * SCR + BM * (WN * 8 + 8) <= A_BYTES, "row statistics beside the epilogue scratch");
+                resid_ln_epilogue<T, MI, NI, TM, TN, BM>(p, acc, cur.m0, cur.n0, wm, wn, lane, tid, scr, scratch0 + HW * SCR,
+                                                         cur.m_lim, cur.row_tile);
+            } else
             gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH, true>(p, acc, cur.m0, cur.n0, wm, wn, lane, scr, [&]() {
                 if (dyn && has_next && tid == 0) drawn = tq.draw();
             }, TALL ? cur.m_lim : -1);
@@ -1321,12 +1580,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #undef ME_STAMP
 #undef ME_PHASE
 
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, int WSLOTS = 3, bool LNF = false>
 void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = (2 * BM + WSLOTS * BN) * 128;
     static_assert(smem <= 160 * 1024, "the tile's rings exceed a CU's LDS");
     ME_CHECK(p.K >= 128, ME_ERR_BAD_SHAPE, "gemm: the two-group kernel needs K >= 128 (K = %d)", p.K);
-    auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI, WSLOTS>;
+    auto kern = gemm_pp_kernel<T, BM, BN, WM, WN, AMODE, EPI, WSLOTS, LNF>;
     static PerDeviceOnce once;
     const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -2051,7 +2310,12 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
                     fail(ME_ERR_BAD_ARG, "gemm: the halo tile is a 3x3 convolution");     \
                 break;                                                                    \
             case 10: /* 352-row two-group tile, two weight slots: one exact round where 256-row tiles leave a tail */ \
-                if constexpr (AMODE == A_PLAIN && (EPI == EPI_STORE || EPI == EPI_RESID_SCALE))   \
+                if constexpr (AMODE == A_PLAIN && EPI == EPI_RESID_SCALE) {                \
+                    if (p.ln_out16)                                                       \
+                        gemm_launch_pp<T, 352, 256, 2, 4, AMODE, EPI, 2, true>(p, stream); \
+                    else                                                                  \
+                        gemm_launch_pp<T, 352, 256, 2, 4, AMODE, EPI, 2>(p, stream);      \
+                } else if constexpr (AMODE == A_PLAIN && EPI == EPI_STORE)                \
                     gemm_launch_pp<T, 352, 256, 2, 4, AMODE, EPI, 2>(p, stream);          \
                 else                                                                      \
                     fail(ME_ERR_BAD_ARG, "gemm: the 352-row tile takes plain linears with store / residual epilogues only"); \

@@ -285,6 +285,7 @@ struct MergedVit {
     int64_t row_main, row_img, row_fov;  // first row of each ViT
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
+    bool xn_is_norm1 = false;  // xn already holds norm1 of the block about to run (written by the block before)
     float* fin32 = nullptr;
     // ME_DTYPE_FP8: xn and hid hold e4m3 bytes, with their block scales (activation layout, Rtot / 128 tiles)
     uint8_t *xn_s = nullptr, *hid_s = nullptr, *att8 = nullptr, *att_s = nullptr;
@@ -430,8 +431,25 @@ struct MergedVit {
     // ... or the residual update x += gamma * (A W^T + b) (proj, fc2).  On the two-group 256x256 tile: the
     // patch encoder's rows alone take 160x128 (two exact rounds), but with the small segments' 24 tiles more
     // the 340 tiles of 256x256 (two rounds) win: 25.5 vs 26.0 ms per step against separate launches.
-    void resid_all(const char* A, int K, const void* w0, const float* bb0, const float* g0, const void* w1,
-                   const float* bb1, const float* g1, const void* w2, const float* bb2, const float* g2) {
+    // LayerNorm weights of the three physical segments for a launch that normalises the rows it updates
+    struct LnSet {
+        const float *w0 = nullptr, *b0 = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    };
+    // The residual update and the LayerNorm behind it in one launch (gemm_core.h resid_ln_epilogue): 16-bit contexts, the
+    // 352-row tile, C in {256, 512, 1024}.  When it applies it applies at EVERY batch size (the tall tile is then taken
+    // whatever tall_tile_wins says), so that a row's statistics are summed in the same order whatever batch the row is
+    // part of: a batch stays a loop of batch-one calls bit for bit.  ME_LN_FUSE=0: the stand-alone LayerNorm launches.
+    bool ln_fusable() const {
+        static const bool enabled = !(getenv("ME_LN_FUSE") && atoi(getenv("ME_LN_FUSE")) == 0);
+        static const bool tall = !(getenv("ME_GEMM_TALL") && atoi(getenv("ME_GEMM_TALL")) == 0);
+        static const bool pp192 = getenv("ME_GEMM_PP192") != nullptr;
+        const int C = ctx->C();
+        return enabled && tall && !pp192 && !ctx->fp8 && (C == 256 || C == 512 || C == 1024);
+    }
+    // returns true when xn holds LayerNorm(ln) of the updated rows
+    bool resid_all(const char* A, int K, const void* w0, const float* bb0, const float* g0, const void* w1,
+                   const float* bb1, const float* g1, const void* w2, const float* bb2, const float* g2,
+                   const LnSet* ln = nullptr) {
         const int C = ctx->C();
         GemmParams p = base_params();
         p.M = (int)Rtot, p.N = C, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = bb0, p.gamma = g0;
@@ -446,12 +464,22 @@ struct MergedVit {
         static const bool use_pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const bool pp = C >= 256 && K >= 128;
         const bool pp192 = pp && K <= 1024 && use_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
+        if (ln && pp && ln_fusable()) {
+            const size_t row_tiles = (size_t)seg_row_tiles<352>((int)Rtot, (int)seg1, (int)seg2);
+            p.ln_out16 = xn, p.ln_eps = ctx->cfg.ln_eps;
+            p.ln_w = ln->w0, p.ln_b = ln->b0, p.ln_w_s1 = ln->w1, p.ln_b_s1 = ln->b1, p.ln_w_s2 = ln->w2, p.ln_b_s2 = ln->b2;
+            p.ln_stats = (unsigned long long*)site_buf(ctx, "vitm.ln.stats", row_tiles * (size_t)(C / 256) * 352 * 8);
+            p.ln_count = (unsigned*)site_buf(ctx, "vitm.ln.count", row_tiles * 64);   // zero when allocated, never reset
+            gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, 10);
+            return true;
+        }
         if (pp && !pp192 && tall_tile_wins(p)) {
             gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, 10);
-            return;
+            return false;
         }
-        if (pp && !pp192 && launch_with_short_tail(p, EPI_RESID_SCALE, w1, bb1, g1, w2, bb2, g2)) return;
+        if (pp && !pp192 && launch_with_short_tail(p, EPI_RESID_SCALE, w1, bb1, g1, w2, bb2, g2)) return false;
         gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, s, pp192 ? 5 : (pp ? 0 : -1));
+        return false;
     }
 
     // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales
@@ -540,15 +568,28 @@ struct MergedVit {
             if (taps.fn) taps.fn(taps.user, i, tok + row_main * C);
             return;
         }
-        set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
-        layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        // norm1: written by the previous block's fc2 launch where the LayerNorm rides in the residual epilogue
+        if (!xn_is_norm1) {
+            set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
+            layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        }
+        xn_is_norm1 = false;
         gemm_all(xn, C, b0.qkv_w, b1.qkv_w, b2.qkv_w, b0.qkv_b, b1.qkv_b, b2.qkv_b, 3 * C, qkv, ACT_NONE, C);
         attention_launch(qkv, att, W0 + W1 * (fov ? 2 : 1), T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
-        resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
-        set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
-        layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        const LnSet ln2{b0.ln2_w, b0.ln2_b, b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b};
+        if (!resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1, &ln2)) {
+            set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
+            layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
+        }
         gemm_all(xn, C, b0.fc1_w, b1.fc1_w, b2.fc1_w, b0.fc1_b, b1.fc1_b, b2.fc1_b, 4 * C, hid, ACT_GELU);
-        resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2);
+        LnSet next;
+        const bool has_next = i + 1 < ctx->cfg.depth;
+        if (has_next) {
+            const VitBlockW &n0 = p0.blocks[i + 1], &n1 = p1.blocks[i + 1], &n2 = p2.blocks[i + 1];
+            next = LnSet{n0.ln1_w, n0.ln1_b, n1.ln1_w, n1.ln1_b, n2.ln1_w, n2.ln1_b};
+        }
+        xn_is_norm1 = resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2,
+                                has_next ? &next : nullptr);
         if (taps.fn) taps.fn(taps.user, i, tok + row_main * C);
     }
 

@@ -210,6 +210,77 @@ def _segmented_linear(ctx, dtype, M, N, K, seg1, seg2, cfg, resid, seed, act=0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [
+    # (M, N, K, seg1, seg2): one column tile (no exchange); two and four column tiles; ragged last row tiles; three
+    # segments with their own GEMM and LayerNorm weights; more row tiles than resident workgroups (the persistent
+    # kernel's second and third rounds wait for neighbours of their own round); the step's own shape
+    (700, 256, 128, 0, 0), (1000, 512, 256, 0, 0), (353, 1024, 128, 0, 0), (3000, 1024, 256, 768, 1536),
+    (2500, 512, 128, 600, 1300), (60000, 1024, 128, 768, 1536), (21760, 1024, 1024, 768, 1536),
+])
+def test_linear_residual_layernorm_fused(dtype, shape):
+    """vit.rs:165-169: the residual update with the next sublayer's LayerNorm in the same launch (gemm_core.h
+    resid_ln_epilogue).  x32 is bit for bit what the plain residual launch on the same tile writes; the normalised rows
+    are held to an fp64 LayerNorm of those x32 values (one 16-bit rounding, statistics summed in f32); a second and
+    third launch on the same buffers (the arrival counters are never reset) reproduce themselves from the same input."""
+    import ctypes as C
+    M, N, K, seg1, seg2 = shape
+    ctx = ctx_for("tiny", dtype)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = dev16(torch.randn(M, K, generator=g), dtype)
+    ws = [dev16(torch.randn(N, K, generator=g) / math.sqrt(K), dtype) for _ in range(3)]
+    bs = [torch.randn(N, generator=g).cuda() for _ in range(3)]
+    gs = [(0.05 + 0.15 * torch.rand(N, generator=g)).cuda() for _ in range(3)]
+    lw = [(1.0 + 0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    lb = [(0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    x0 = torch.randn(M, N, generator=g) * 2.0
+    x0[:, 7] += 40.0                                 # an outlier channel: mean and variance far from 0 / 1
+    x0[::3] *= 10.0                                   # rows of very different scale
+    x0 = x0.cuda()
+    plain = x0.clone()
+    fused = x0.clone()
+    xn = torch.full((M + 1, N), 7.0, dtype=TORCH16[dtype], device="cuda")     # a guard row behind the output
+    torch.cuda.synchronize()
+    _check(ctx, ctx.lib.me_op_linear_segments(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), None,
+                                              ptr(plain), 0, 10))
+    eps = 1e-5
+    _check(ctx, ctx.lib.me_op_linear_residual_layernorm(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs),
+                                                        arr(lw), arr(lb), eps, ptr(fused), ptr(xn)))
+    ctx.synchronize()
+    assert ctx.status_flags() == 0
+    assert torch.equal(fused, plain)
+    assert bool((xn[M] == 7.0).all())
+    bounds = [0, seg1 if seg1 else M, (seg2 if seg2 else M) if seg1 else M, M]
+    ref = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    xd = fused.double()
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi > lo:
+            ref[lo:hi] = F.layer_norm(xd[lo:hi], (N,), lw[i].double(), lb[i].double(), eps)
+    err = (xn[:M].double() - ref).abs()
+    tol = OUT_EPS[dtype] * ref.abs().clamp_min(1.0) + 2e-5 * ref.abs().clamp_min(1.0)
+    assert bool((err <= 1.01 * tol).all()), float((err / tol).max())
+    assert rel_l2(xn[:M].float(), ref) < OUT_EPS[dtype]
+    # the stand-alone kernel on the same rows: the same values up to the rounding of the last bit of a few of them
+    if seg1 == 0:
+        alone = torch.empty(M, N, dtype=TORCH16[dtype], device="cuda")
+        _check(ctx, ctx.lib.me_op_layernorm(ctx.handle, ptr(fused), ptr(lw[0]), ptr(lb[0]), ptr(alone), None, M, N, eps))
+        ctx.synchronize()
+        differ = float((alone != xn[:M]).float().mean())
+        assert differ < 2e-3 and rel_l2(alone.float(), xn[:M].float()) < 0.2 * OUT_EPS[dtype], differ
+    # again, twice, from the same input: same bits (counters keep counting, nothing is reset)
+    for _ in range(2):
+        again = x0.clone()
+        xn2 = torch.empty(M, N, dtype=TORCH16[dtype], device="cuda")
+        torch.cuda.synchronize()
+        _check(ctx, ctx.lib.me_op_linear_residual_layernorm(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs),
+                                                            arr(gs), arr(lw), arr(lb), eps, ptr(again), ptr(xn2)))
+        ctx.synchronize()
+        assert torch.equal(again, fused) and torch.equal(xn2, xn[:M])
+    assert ctx.status_flags() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("resid", [False, True])
 @pytest.mark.parametrize("shape", [
     # (M, N, K, seg1, seg2): one segment with a ragged last tile; the merged ViT row space of one image in small (three
