@@ -473,6 +473,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                                               Hook after_loads = Hook(), int m_lim = -1) {
     // rows >= Mrows are not stored: p.M, or the end of the tile's row segment (seg_tile_rows)
     const int Mrows = m_lim < 0 ? p.M : m_lim;
+    // (the epilogue's per-lane constants are derived behind an opaque use of the lane index: see resid_ln_epilogue)
+    asm volatile("" : "+v"(lane));
     const int frow = lane & 15;
     const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
     if constexpr (EPI == EPI_HEAD_FINAL) {
