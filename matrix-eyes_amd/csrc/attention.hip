@@ -46,6 +46,14 @@ struct Mfma32<bf16> {
 __device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
+// the same by LDS byte address
+__device__ __forceinline__ s16x4 lds_read_tr16_at(unsigned a) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)a);
+}
+template <typename F>
+__device__ __forceinline__ F lds_read_frag(unsigned a) {
+    return *(const __attribute__((address_space(3))) F*)(size_t)a;
+}
 
 constexpr int KT = 64;            // keys per LDS tile
 constexpr int TILE_BYTES = KT * 128;
@@ -458,12 +466,13 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
     // K/V staging by LDS-DMA (see the kernel above): wave w stages pieces 2w and 2w + 1 of K and of V
     const int st_row = lane >> 3, st_slot = lane & 7;
     const unsigned row_bytes = (unsigned)ldq * 2u;
-    unsigned koff[2], voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rr = (2 * wave + i) * 8 + st_row;
-        koff[i] = (unsigned)rr * row_bytes + ((st_slot ^ ((rr >> 1) & 7)) << 4);
-        voff[i] = (unsigned)rr * row_bytes + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4);
+    // offsets of this wave's FIRST piece (rows 16 wave + st_row); the second piece, eight rows on, is derived from them
+    // where it is issued: K's swizzle (rr >> 1) & 7 changes by 4 (chunk ^ 4 = byte offset ^ 64), V's (rr >> 1) & 1 does not
+    unsigned koff0, voff0;
+    {
+        const int rr = (2 * wave) * 8 + st_row;
+        koff0 = (unsigned)rr * row_bytes + ((st_slot ^ ((rr >> 1) & 7)) << 4);
+        voff0 = (unsigned)rr * row_bytes + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4);
     }
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
     const char* kwin = uniform_ptr((const char*)(kbase + row0 * ldq));
@@ -474,11 +483,12 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
         const char* kt_k = uniform_ptr(kwin + (size_t)kt * KT * row_bytes);
         const char* kt_v = uniform_ptr(vwin + (size_t)kt * KT * row_bytes);
         if ((kt + 1) * KT <= tokens) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                glds16_raw(kt_k, koff[i], dst + i * 1024);
-                glds16_raw(kt_v, voff[i], dst + TILE_BYTES + i * 1024);
-            }
+            unsigned k0 = koff0, v0 = voff0;
+            asm volatile("" : "+v"(k0), "+v"(v0));  // (the derived offsets stay temporaries: hoisted, they spill)
+            glds16_raw(kt_k, k0, dst);
+            glds16_raw(kt_v, v0, dst + TILE_BYTES);
+            glds16_raw(kt_k, (k0 ^ 64u) + 8u * row_bytes, dst + 1024);
+            glds16_raw(kt_v, v0 + 8u * row_bytes, dst + TILE_BYTES + 1024);
         } else {  // the ragged last tile: rows past the end read the last row (masked or unused below)
             const int last = tokens - 1 - kt * KT;  // >= 0
 #pragma unroll
@@ -491,12 +501,22 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
         }
     };
 
-    const int k_rd = r * 128;
-    const int k_swz = (r >> 1) & 7;
+    // Fragment read addresses as TWO per-lane constants beside immediates and XORs with immediates (written out, the
+    // swizzles give the compiler a register per (half, sub-block, d, st) combination, the 128-register variant spills
+    // them into the tile loop, and every reload's vmcnt wait there also waits for the next tile's LDS-DMA):
+    //   K: row = 32 ks + r, chunk 2 st + h at slot (2 st + h) ^ ((r >> 1) & 7) = 2 (st ^ t) + (h ^ u): byte offset
+    //      k_lane ^ (st << 5) + ks * 4096, k_lane being the offset of st = 0
+    //   V (transposed read, group g = lane >> 4, il = lane & 15): row = 32 ks + 16 s2 + 8 half + 4 h + (il >> 2), chunk
+    //      (4 d + 2 (g & 1) + (il >> 1 & 1)) ^ (row >> 1 & 1) << 2 -- the swizzle bit is (il >> 3) & 1 for every row of the
+    //      lane, so it only exchanges the two d blocks: v_lane ^ (d << 6) + (32 ks + 16 s2 + 8 half) * 128
     const int il = lane & 15;
-    const int v_qrow = il >> 2, v_p = il & 3;
-    const int v_dhalf = (lane >> 4) & 1;
-
+    int k_lane, v_lane;
+    {
+        const int k_swz = (r >> 1) & 7;
+        k_lane = r * 128 + ((h ^ k_swz) << 4);
+        const int v_qrow = il >> 2, v_p = il & 3, v_dhalf = (lane >> 4) & 1;
+        v_lane = (4 * h + v_qrow) * 128 + ((2 * v_dhalf + (v_p >> 1)) << 4) + ((v_p & 1) << 3) + (((v_qrow >> 1) & 1) << 6);
+    }
     f32x16 o[2], lsum, negm;
     o[0] = f32x16{0};
     o[1] = f32x16{0};
@@ -549,40 +569,42 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
         }
 #endif
         ATT_PH(1);
-        const char* kb = smem + slot * (2 * TILE_BYTES);
-        const char* vb = kb + TILE_BYTES;
+        // this tile's fragment addresses (LDS byte addresses; the slots are 16 KiB-aligned, so the XORs below stay inside)
+        unsigned ka = smem_base + slot * (2 * TILE_BYTES) + (unsigned)k_lane;
+        unsigned va = smem_base + slot * (2 * TILE_BYTES) + TILE_BYTES + (unsigned)v_lane;
+        asm volatile("" : "+v"(ka), "+v"(va));  // (derived per tile: hoisted, the variants spill)
         slot ^= 1;
 
-        if (active) {
-            // ---- S' = K Qc^T - m' for the two 32-key halves of the tile
-            f32x16 s[2];
+        auto part = [&](auto k0_tag, auto nks_tag, bool first_part) {
+            constexpr int K0 = decltype(k0_tag)::value, NKS = decltype(nks_tag)::value;
+            // ---- S' = K Qc^T - m' for 32-key halves K0 .. K0 + NKS - 1 of the tile
+            f32x16 s[NKS];
 #ifdef ME_ATT_STAMPS
             if (abl & 8) {
-                s[0] = negm, s[1] = negm;
-                asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+                for (int ks = 0; ks < NKS; ++ks) s[ks] = negm;
+                asm volatile("" : "+v"(s[0]), "+v"(s[NKS - 1]));
             } else
 #endif
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
-                    const frag kf = *reinterpret_cast<const frag*>(
-                        kb + ks * 32 * 128 + k_rd + (((2 * st + h) ^ k_swz) << 4));
+                    const frag kf = lds_read_frag<frag>((ka ^ (unsigned)(st << 5)) + (K0 + ks) * 32 * 128);
                     s[ks] = Mfma32<T>::run(kf, qf[st], st == 0 ? negm : s[ks]);
                 }
             }
 #ifdef ME_ATT_STAMPS
-            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+            asm volatile("" : "+v"(s[0]), "+v"(s[NKS - 1]));
 #endif
             ATT_PH(2);
             // ---- does the running maximum grow?
             float mloc = -INFINITY;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     if (TAIL) {
-                        const int key = kt * KT + ks * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                        const int key = kt * KT + (K0 + ks) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
                         if (key >= tokens) s[ks][g] = -INFINITY;
                     }
                     mloc = fmaxf(mloc, s[ks][g]);
@@ -602,16 +624,20 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
             // the same relative precision in the 16-bit P operand, and O and l carry the same factor, so the quotient is
             // unchanged.  With 32 queries to a wave SOME maximum grows in nearly every tile (the branch, 60 vector
             // instructions, would run every time); past the threshold almost never after the first tile.
-            if (FIRST || __any(mloc > defer_thr)) {
-                const float delta = FIRST ? mloc : fmaxf(mloc, 0.f);
-                if (!FIRST) {
+            if ((FIRST && first_part) || __any(mloc > defer_thr)) {
+                const float delta = (FIRST && first_part) ? mloc : fmaxf(mloc, 0.f);
+                if (!(FIRST && first_part)) {
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int g = 0; g < 16; ++g) o[0][g] *= alpha, o[1][g] *= alpha, lsum[g] *= alpha;
                 }
                 m_run += delta;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) s[0][g] -= delta, s[1][g] -= delta, negm[g] = -m_run;
+                for (int g = 0; g < 16; ++g) negm[g] = -m_run;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) s[ks][g] -= delta;
             }
             ATT_PH(3);
             // ---- p = exp2(S')  (raw v_exp_f32: the argument is <= 0, results below 2^-126 may flush to 0)
@@ -619,22 +645,22 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
             if (!(abl & 2))
 #endif
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) s[ks][g] = __builtin_amdgcn_exp2f(s[ks][g]);
 
 #ifdef ME_ATT_STAMPS
-            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+            asm volatile("" : "+v"(s[0]), "+v"(s[NKS - 1]));
 #endif
             ATT_PH(4);
             // ---- O^T += V^T P^T,  l += 1^T P^T
 #ifdef ME_ATT_STAMPS
             if (abl & 4) {
-                asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+                asm volatile("" : "+v"(s[0]), "+v"(s[NKS - 1]));
             } else
 #endif
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     frag pf;
@@ -643,22 +669,18 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
                     lsum = Mfma32<T>::run(ones, pf, lsum);
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        s16x4 half0, half1;
-                        {
-                            const int row = ks * 32 + 16 * s2 + 4 * h + v_qrow;
-                            const int chunk = (d * 4 + 2 * v_dhalf + (v_p >> 1)) ^ (((row >> 1) & 1) << 2);
-                            half0 = lds_read_tr16(vb + row * 128 + (chunk << 4) + ((v_p & 1) << 3));
-                        }
-                        {
-                            const int row = ks * 32 + 16 * s2 + 8 + 4 * h + v_qrow;
-                            const int chunk = (d * 4 + 2 * v_dhalf + (v_p >> 1)) ^ (((row >> 1) & 1) << 2);
-                            half1 = lds_read_tr16(vb + row * 128 + (chunk << 4) + ((v_p & 1) << 3));
-                        }
+                        const unsigned vp = (va ^ (unsigned)(d << 6)) + ((K0 + ks) * 32 + 16 * s2) * 128;
+                        const s16x4 half0 = lds_read_tr16_at(vp), half1 = lds_read_tr16_at(vp + 8 * 128);
                         typedef short s16x8 __attribute__((__vector_size__(16)));
                         const s16x8 both = __builtin_shufflevector(half0, half1, 0, 1, 2, 3, 4, 5, 6, 7);
                         o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, both), pf, o[d]);
                     }
                 }
+        };
+        // (one part = both halves side by side.  The halves one after the other through ONE score block, with the row sums
+        // on the vector pipe, fit 128 registers and four waves per SIMD: 83.8 us against 85.3, nothing in the step)
+        if (active) {
+            part(std::integral_constant<int, 0>(), std::integral_constant<int, 2>(), true);
         }  // active
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the
                                                              // barrier that lets its slot be restaged

@@ -1,6 +1,6 @@
 """attention kernel variants at the step's shape (37 windows x 577 tokens x 16 heads), random data, interleaved rounds
 in ONE process (cdna_hip_programming.md rule 24): the round-1 kernel (ME_ATT_V=1) against attention2_kernel with its
-registers capped for 2 / 3 / 4 waves per SIMD, plain and pre-scaled Q.  Prints median / min us and TFLOP/s on the real
+deferred and exact running maximum.  Prints median / min us and TFLOP/s on the real
 FLOPs (4 * windows * heads * tokens^2 * 64)."""
 import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,13 +21,10 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
     ("v1 (round 1 kernel)", {"ME_ATT_V": "1"}, False),
-    ("v2 thr8", {}, False),
     ("v2 thr8 prescaled", {}, True),
     ("v2 thr0 prescaled", {"ME_ATT_THR": "0"}, True),
-    ("v2 thr4 prescaled", {"ME_ATT_THR": "4"}, True),
-    ("v2 thr8 pre minw2", {"ME_ATT_MINW": "2"}, True),
 ]
-KEYS = ("ME_ATT_V", "ME_ATT_MINW", "ME_ATT_THR")
+KEYS = ("ME_ATT_V", "ME_ATT_THR")
 
 
 def run(env, pre):
