@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256, MINW) void attention_kernel(const T* __restric
 // beside two or three others, barely moves with the instruction count (phase stamps and timing-only ablations:
 // profiles/r04_attention_ablations.txt).  What that points at is two query blocks per wave (the second block's MFMAs
 // under the first one's softmax), not fewer instructions.
-template <typename T, int MINW>
+// HALVES: the two 32-key halves of a tile one after the other through ONE score block, row sums on the vector pipe:
+// 32 registers less (128 VGPRs, four waves per SIMD) than with the halves side by side and the sums on the matrix pipe
+template <typename T, int MINW, bool HALVES>
 __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                int tokens, int heads, int ngroups,
                                                                RowSegs segs, uint8_t* __restrict__ out8,
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
     lsum = f32x16{0};
     negm = f32x16{0};
     float m_run = 0.f;  // the running maximum (exp2 units); negm == -m_run in all sixteen registers
+    float l_run = 0.f;  // HALVES: this lane's part of the row sum
     frag ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
@@ -629,7 +632,13 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
                 if (!(FIRST && first_part)) {
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) o[0][g] *= alpha, o[1][g] *= alpha, lsum[g] *= alpha;
+                    for (int g = 0; g < 16; ++g) o[0][g] *= alpha, o[1][g] *= alpha;
+                    if constexpr (HALVES) {
+                        l_run *= alpha;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) lsum[g] *= alpha;
+                    }
                 }
                 m_run += delta;
 #pragma unroll
@@ -666,7 +675,12 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
                     frag pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (T)s[ks][8 * s2 + j];
-                    lsum = Mfma32<T>::run(ones, pf, lsum);
+                    if constexpr (HALVES) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) l_run += s[ks][8 * s2 + j];
+                    } else {
+                        lsum = Mfma32<T>::run(ones, pf, lsum);
+                    }
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         const unsigned vp = (va ^ (unsigned)(d << 6)) + ((K0 + ks) * 32 + 16 * s2) * 128;
@@ -677,10 +691,13 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
                     }
                 }
         };
-        // (one part = both halves side by side.  The halves one after the other through ONE score block, with the row sums
-        // on the vector pipe, fit 128 registers and four waves per SIMD: 83.8 us against 85.3, nothing in the step)
         if (active) {
-            part(std::integral_constant<int, 0>(), std::integral_constant<int, 2>(), true);
+            if constexpr (HALVES) {
+                part(std::integral_constant<int, 0>(), std::integral_constant<int, 1>(), true);
+                part(std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), false);
+            } else {
+                part(std::integral_constant<int, 0>(), std::integral_constant<int, 2>(), true);
+            }
         }  // active
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's LDS reads are done before the
                                                              // barrier that lets its slot be restaged
@@ -702,7 +719,8 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
         else
             tile(nfull - 1, std::false_type(), std::true_type());
     }
-    l_tot = lsum[0];
+    if constexpr (HALVES) l_tot = l_run + __shfl_xor(l_run, 32);
+    else l_tot = lsum[0];
     if (tail_key) {
         // 577 = 9 x 64 + 1: the single key of the last tile (row 0 of the tile staged last) as a rank-one update
         wait_vmcnt<0>();
@@ -822,14 +840,25 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
         // reference point is the exact running maximum (tools/attn_ab.py compares the two)
         const char* th = getenv("ME_ATT_THR");
         const float defer_thr = th ? (float)atof(th) : 8.0f;
-        if (dtype == ME_DTYPE_F16)
-            hipLaunchKernelGGL((attention2_kernel<f16, 3>), grid, dim3(256), 0, stream, (const f16*)qkv, (f16*)out, tokens,
-                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);
-        else if (dtype == ME_DTYPE_BF16)
-            hipLaunchKernelGGL((attention2_kernel<bf16, 3>), grid, dim3(256), 0, stream, (const bf16*)qkv, (bf16*)out, tokens,
-                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);
-        else
-            fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
+        // Two forms (HALVES above), within 1.5 % of each other from 37 to 296 windows (profiles/r04_attention_ablations.txt:
+        // three waves per SIMD with the leaner tile against four with the vector-pipe row sums).  ONE form runs at every
+        // size -- their row sums round differently, and a batch must equal a loop of batch-one calls bit for bit;
+        // ME_ATT_HALVES=1 (development) selects the other.
+        const char* hv = getenv("ME_ATT_HALVES");
+        const bool halves = hv && atoi(hv) != 0;
+#define ME_ATT2(T)                                                                                                          \
+    do {                                                                                                                    \
+        if (halves)                                                                                                         \
+            hipLaunchKernelGGL((attention2_kernel<T, 4, true>), grid, dim3(256), 0, stream, (const T*)qkv, (T*)out, tokens, \
+                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);                                 \
+        else                                                                                                                \
+            hipLaunchKernelGGL((attention2_kernel<T, 3, false>), grid, dim3(256), 0, stream, (const T*)qkv, (T*)out, tokens, \
+                               heads, ngroups, segs, out8, out8_scale, out8_mt, defer_thr);                                 \
+    } while (0)
+        if (dtype == ME_DTYPE_F16) ME_ATT2(f16);
+        else if (dtype == ME_DTYPE_BF16) ME_ATT2(bf16);
+        else fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
+#undef ME_ATT2
         ME_HIP(hipGetLastError());
         return;
     }

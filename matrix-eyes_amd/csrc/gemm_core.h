@@ -1281,7 +1281,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // {first, step, clamp} instead of one register per piece (22 VGPRs of the two tiles in flight become 4)
     constexpr bool TALL = BM > 256;
     static_assert(!TALL || AMODE == A_PLAIN, "the tall tile's affine source offsets need row-major activations");
-    const int ntiles = (TALL ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    // LNF: the column tiles of a row tile must run in the SAME round of the persistent loop (they wait for one another's
+    // statistics: a tile that waited for a later round's tile would at best serialise the rounds and at worst wait for
+    // a workgroup that waits for it).  The walk above guarantees that only when an XCD's run is a whole number of
+    // patches, so the fused launch has its own: virtual tile vb = (x, j) with x = vb & 7 its XCD and j = vb >> 3 its
+    // place there; column tile j % nbn of row tile (j / nbn) * 8 + x.  A round gives an XCD 32 consecutive j -- 32 / nbn
+    // whole row tiles, each with all its column tiles on neighbouring workgroups; an XCD's 32 tiles of a round are
+    // again 8 row panels x 4 weight panels.  Row tiles past the last one (the padding of the last round) do not exist.
+    const int lnf_nbn = (p.N + BN - 1) / BN, lnf_nbm = TALL ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : 0;
+    auto lnf_row_tile = [&](int vb) { return ((vb >> 3) / lnf_nbn) * 8 + (vb & 7); };
+    const int ntiles = LNF ? ((lnf_nbm + 7) / 8) * 8 * lnf_nbn
+                           : (TALL ? seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : (p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if constexpr (LNF) {
+        if (lnf_row_tile(blockIdx.x) >= lnf_nbm) return;  // uniform; this workgroup's later tiles do not exist either
+    }
 
     const int srow = lane >> 3, sslot = lane & 7;
     struct Src {
@@ -1294,7 +1307,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     };
     auto pixel_of = [&](int gm) -> int64_t { return conv_pixel(p, gm); };
     auto setup = [&](Src& t, int vb) {
-        tile_origin<BM, BN, TALL>(p, vb, ntiles, t.m0, t.n0, &t.m_lim, &t.row_tile);
+        if constexpr (LNF) {
+            t.row_tile = lnf_row_tile(vb);
+            t.n0 = ((vb >> 3) % lnf_nbn) * BN;
+            seg_tile_rows<BM>(p, t.row_tile, t.m0, t.m_lim);
+        } else {
+            tile_origin<BM, BN, TALL>(p, vb, ntiles, t.m0, t.n0, &t.m_lim, &t.row_tile);
+        }
         if constexpr (TALL) {
             // piece i of a lane: row (i * HW + gw) * 8 + srow of the tile, always the same 16-byte chunk position
             // (the swizzle repeats every 16 rows) -- offsets are affine in i; rows beyond the operand's last row
@@ -1450,7 +1469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     ME_STAMP();
 
     while (true) {
-        const bool has_next = next_vb >= 0 && next_vb < ntiles;
+        const bool has_next = next_vb >= 0 && next_vb < ntiles && (!LNF || lnf_row_tile(next_vb) < lnf_nbm);
         if (has_next) setup(nxt, next_vb);
         f32x4 acc[MI][NI];
 #pragma unroll
@@ -1598,15 +1617,22 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
         r -= r % 8;
         return r < 8 ? 8 : r;
     });
-    const int64_t ntiles = (BM > 256 ? (int64_t)seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : cdiv(p.M, BM)) * cdiv(p.N, BN);
+    int64_t ntiles = (BM > 256 ? (int64_t)seg_row_tiles<BM>(p.M, p.seg1, p.seg2) : cdiv(p.M, BM)) * cdiv(p.N, BN);
+    if (LNF) ntiles = cdiv((int64_t)seg_row_tiles<BM>(p.M, p.seg1, p.seg2), 8) * 8 * cdiv(p.N, BN);  // the kernel's padded walk
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
     int64_t grid = ntiles < resident ? ntiles : resident;
+    if (LNF) {
+        // a round is a whole number of row tiles per XCD, and every workgroup of it must be resident (they wait for one another)
+        const int64_t unit = 8 * cdiv(p.N, BN);
+        ME_CHECK(resident >= unit, ME_ERR_HIP, "gemm: the fused LayerNorm needs %lld resident workgroups", (long long)unit);
+        grid -= grid % unit;
+    }
     // diagnostic (tools/dual_stream_probe.py): cap the persistent grid so that two launches on two streams share
     // the chip instead of the first one taking every CU until it ends
     static const int grid_limit = getenv("ME_GEMM_GRID_LIMIT") ? atoi(getenv("ME_GEMM_GRID_LIMIT")) : 0;
-    if (grid_limit >= 8 && grid > grid_limit) grid = grid_limit - grid_limit % 8;
-    if (p.grid_cap >= 8 && grid > p.grid_cap) grid = p.grid_cap - p.grid_cap % 8;
+    if (!LNF && grid_limit >= 8 && grid > grid_limit) grid = grid_limit - grid_limit % 8;
+    if (!LNF && p.grid_cap >= 8 && grid > p.grid_cap) grid = p.grid_cap - p.grid_cap % 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, stream, p);
     ME_HIP(hipGetLastError());
 }

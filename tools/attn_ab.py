@@ -21,10 +21,10 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
     ("v1 (round 1 kernel)", {"ME_ATT_V": "1"}, False),
-    ("v2 thr8 prescaled", {}, True),
-    ("v2 thr0 prescaled", {"ME_ATT_THR": "0"}, True),
+    ("v2 side by side, 3 waves", {"ME_ATT_HALVES": "0"}, True),
+    ("v2 halves, 4 waves", {"ME_ATT_HALVES": "1"}, True),
 ]
-KEYS = ("ME_ATT_V", "ME_ATT_THR")
+KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES")
 
 
 def run(env, pre):
