@@ -250,6 +250,8 @@ struct GemmParams {
     float ln_eps;
     unsigned long long* ln_stats;
     unsigned* ln_count;
+    // development A/B (ME_GELU_BATCH=0): fc1's GELU four values at a time instead of a pass's sixteen at once
+    int32_t gelu_per_granule;
     // persistent kernels: at most this many workgroups (a multiple of 8), so that a launch on another stream finds
     // free CUs beside this one; 0: as many as are resident
     int32_t grid_cap;

@@ -162,6 +162,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
     // workgroup, too coarse for a late workgroup to hand work to its neighbours.
     p.queue = dynamic_tile_order() ? queue_for_stream(stream) : nullptr;
     p.status = current_status_word();
+    {
+        const char* gb = getenv("ME_GELU_BATCH");
+        p.gelu_per_granule = gb && atoi(gb) == 0;
+    }
     static const int patch_rows = getenv("ME_GEMM_PATCH_ROWS") ? atoi(getenv("ME_GEMM_PATCH_ROWS")) : 0;  // A/B knob
     p.patch_rows = patch_rows;
     ME_CHECK(p.M > 0 && p.N > 0 && p.K > 0, ME_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", p.M,
