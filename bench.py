@@ -34,7 +34,7 @@ VIT_WINDOW_GFLOP = 382.13
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_PEAK_TFLOPS_FP8 = 5000.0  # dense MX-scaled fp8, MI355X_MICROARCH.md "Peak FP8 MFMA"
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
 
 
 def kernel_source_sha():
@@ -51,7 +51,7 @@ def kernel_source_sha():
 
 def pmc_traffic(kernel_name):
     """(HBM-side bytes per launch, algorithmic bytes per launch, MFMA utilisation, note) of the dominant kernel
-    from the committed rocprofv3 PMC passes (profiles/r03_pmc_kernels.json, written by tools/pmc_collect.py:
+    from the committed rocprofv3 PMC passes (profiles/r04_pmc_kernels.json, written by tools/pmc_collect.py:
     separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/gemm_probe.py on the shapes this kernel
     alternates between in the step).  Both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
     of a wide coalesced stream (MI355X_MICROARCH.md, HBM), so it is doubled; Infinity-Cache hits are included in
@@ -67,7 +67,7 @@ def pmc_traffic(kernel_name):
             return None, None, None, "no PMC pass for this kernel"
         n = float(len(ops))
         return (sum(v["hbm_bytes"] for v in ops) / n, sum(v["algorithmic_bytes"] for v in ops) / n,
-                sum(v["mfma_util"] for v in ops) / n, f"profiles/r03_pmc_kernels.json, source sha {meta['source_sha']}")
+                sum(v["mfma_util"] for v in ops) / n, f"profiles/r04_pmc_kernels.json, source sha {meta['source_sha']}")
     except Exception as e:   # no file: traffic stays null
         return None, None, None, f"no PMC file ({type(e).__name__})"
 

@@ -493,8 +493,10 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     // on 144 - 576 workgroups each -- latency-bound, most of the chip idle -- and depend only on encodings 2 - 4; the
     // encoder's two latent chains (encodings 1 and 0, read by levels 1 and 0 only) are ConvTranspose launches bound by
     // their HBM writes.  The two run side by side: fork behind the encoder trunk, join in front of level 1; the
-    // persistent launches of the main branch leave 64 CUs to the side branch meanwhile.  Same kernels, same order per
-    // buffer: the depth is bit for bit that of the one-stream order.
+    // persistent launches of the main branch leave half of the CUs to the side branch meanwhile.  Same kernels, same
+    // order per buffer: the depth is bit for bit that of the one-stream order.  What it buys is small -- 22.84 -> 22.74 ms
+    // per step (profiles/r04_side_stream.txt): side by side the ConvTranspose launch takes 404 us instead of 242 and the
+    // small convolutions beside it three times their own time; both are short of memory-system bandwidth, not of CUs.
     static const bool overlap_env = !(getenv("ME_OVERLAP_TAIL") && atoi(getenv("ME_OVERLAP_TAIL")) == 0);
     const bool overlap = overlap_env && ctx->overlap_tail && ctx->side_stream && !ctx->progress && !profiler().enabled;
     OutBuf ofov;
@@ -516,7 +518,7 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
         stage_decoder_levels(ctx, batch, false, 3, 2);
         ME_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
         ctx->stream = main_stream;
-        static const int cap = getenv("ME_OVERLAP_CAP") ? atoi(getenv("ME_OVERLAP_CAP")) : 192;
+        static const int cap = getenv("ME_OVERLAP_CAP") ? atoi(getenv("ME_OVERLAP_CAP")) : 128;
         ctx->grid_cap = cap;
         stage_encoder_latents(ctx, batch);
         ctx->grid_cap = 0;

@@ -980,7 +980,7 @@ __device__ __forceinline__ void resid_ln_epilogue(const GemmParams& p, f32x4 (&a
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) {  // seconds: the neighbours are resident and arrive within microseconds
+                if (++spins > (1u << 20)) {  // ~2 s: the neighbours are resident and arrive within microseconds
                     if (p.status) atomicOr(p.status, 2u);
                     break;
                 }
