@@ -23,6 +23,8 @@ pub const ME_ERR_OOM: i32 = 9;
 pub const ME_ERR_OVERFLOW: i32 = 10; // an activation left the f16 operand range (me_status_flags)
 // me_status_flags bits
 pub const ME_STATUS_OVERFLOW_16BIT: i32 = 1;
+/// me_status_flags: a workgroup gave up waiting for its neighbours' LayerNorm statistics (never on a healthy device)
+pub const ME_STATUS_SYNC_TIMEOUT: i32 = 2;
 
 // MFMA operand type
 pub const ME_DTYPE_F16: i32 = 0;
