@@ -564,6 +564,12 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
 void fail_on_overflow(me_ctx* ctx) {
     uint32_t host = 0;
     ME_HIP(hipMemcpy(&host, ctx->status_dev, 4, hipMemcpyDeviceToHost));
+    if (host & ME_STATUS_SYNC_TIMEOUT) {
+        ME_HIP(hipMemset(ctx->status_dev, 0, 4));
+        fail(ME_ERR_HIP,
+             "a workgroup of the fused residual + LayerNorm launch gave up waiting for its neighbours' statistics (another "
+             "process holding the device's CUs?): the depth map is not valid.  ME_LN_FUSE=0 runs the LayerNorm as its own launch");
+    }
     if (host & ME_STATUS_OVERFLOW_16BIT) {
         ME_HIP(hipMemset(ctx->status_dev, 0, 4));
         fail(ME_ERR_OVERFLOW,

@@ -49,6 +49,8 @@ def describe(op, cfg):
         probe, n, k, rows = SHAPES[op]
         resid = probe in ("proj", "fc2")
         out = rows * n * (8 if resid else 2)       # f32 read-modify-write, or one 16-bit store
+        if resid and cfg == 10:
+            out += rows * n * 2 + n * 8            # + the normalised 16-bit rows and the LayerNorm weights (gemm_probe.py runs the fused form)
         bytes_ = rows * k * 2 + n * k * 2 + out + n * 4 * (2 if resid else 1)
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},plain,{'resid_scale' if resid else 'store'}>", bytes_
     if op in SHAPES8:
