@@ -87,6 +87,13 @@ int32_t me_op_linear_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32
                                         int32_t seg2, const void* const W16[3], const float* const bias[3],
                                         const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
                                         float eps, float* x32, void* xn16);
+/* The same launch with the normalised rows written as the next GEMM's MX fp8 operand instead of 16-bit: xn8 [M][N] e4m3
+   bytes and xn_scale, one e8m0 byte per 32 columns in the activation layout of me_op_layernorm_fp8 (ceil(M / 128) tiles
+   of 128 rows) -- what an ME_DTYPE_FP8 context's 16-bit projection hands to fc1. */
+int32_t me_op_linear_residual_layernorm_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
+                                            int32_t seg2, const void* const W16[3], const float* const bias[3],
+                                            const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
+                                            float eps, float* x32, uint8_t* xn8, uint8_t* xn_scale);
 /* me_op_linear_fp8 over up to three row segments with their own weights, as the encoder's merged ViT launches run
    it (pipeline.hip MergedVit): rows [0, seg1) use W8[0] / w_scale[0] / bias[0] (/ gamma[0]), [seg1, seg2) the [1]
    set, [seg2, M) the [2] set; seg1, seg2 multiples of 256, seg2 == 0: two segments, seg1 == 0: one. */

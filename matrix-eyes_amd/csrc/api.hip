@@ -1017,32 +1017,54 @@ int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, cons
     ME_API_END(ctx)
 }
 
-int32_t me_op_linear_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
-                                        int32_t seg2, const void* const W16[3], const float* const bias[3],
-                                        const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
-                                        float eps, float* x32, void* xn16) {
-    ME_API_BEGIN(ctx)
-    ME_CHECK(A16 && W16 && bias && gamma && ln_w && ln_b && x32 && xn16, ME_ERR_BAD_ARG,
-             "me_op_linear_residual_layernorm: null pointer");
+namespace {
+// xn8 != nullptr: the normalised rows as MX fp8 + activation-layout scales (ceil(M / 128) tiles) instead of 16-bit
+void linear_residual_layernorm_impl(me_ctx* ctx, const char* who, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
+                                    int32_t seg2, const void* const W16[3], const float* const bias[3], const float* const gamma[3],
+                                    const float* const ln_w[3], const float* const ln_b[3], float eps, float* x32, void* xn16,
+                                    uint8_t* xn8, uint8_t* xn_scale) {
+    ME_CHECK(A16 && W16 && bias && gamma && ln_w && ln_b && x32 && (xn16 || (xn8 && xn_scale)), ME_ERR_BAD_ARG, "%s: null pointer", who);
     ME_CHECK(seg1 >= 0 && seg2 >= 0 && seg1 <= M && seg2 <= M && (seg2 == 0 || (seg1 > 0 && seg2 > seg1)), ME_ERR_BAD_ARG,
-             "me_op_linear_residual_layernorm: segments %d / %d of %d rows", seg1, seg2, M);
+             "%s: segments %d / %d of %d rows", who, seg1, seg2, M);
     const int nseg = seg1 == 0 ? 1 : (seg2 == 0 ? 2 : 3);
     for (int i = 0; i < nseg; ++i)
-        ME_CHECK(W16[i] && bias[i] && gamma[i] && ln_w[i] && ln_b[i], ME_ERR_BAD_ARG,
-                 "me_op_linear_residual_layernorm: row segment %d without weights", i);
-    ME_CHECK(N == 256 || N == 512 || N == 1024, ME_ERR_BAD_SHAPE, "me_op_linear_residual_layernorm: N = %d not in {256, 512, 1024}", N);
+        ME_CHECK(W16[i] && bias[i] && gamma[i] && ln_w[i] && ln_b[i], ME_ERR_BAD_ARG, "%s: row segment %d without weights", who, i);
+    ME_CHECK(N == 256 || N == 512 || N == 1024, ME_ERR_BAD_SHAPE, "%s: N = %d not in {256, 512, 1024}", who, N);
     GemmParams p = GemmParams();
     p.M = M, p.N = N, p.K = K, p.A = A16, p.lda = K, p.W = W16[0], p.bias = bias[0], p.ldc = N;
     p.seg1 = seg1, p.seg2 = seg2, p.W_s1 = W16[1], p.bias_s1 = bias[1], p.W_s2 = W16[2], p.bias_s2 = bias[2];
     p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
     p.gamma = gamma[0], p.gamma_s1 = gamma[1], p.gamma_s2 = gamma[2], p.res32 = x32, p.out32 = x32;
-    p.ln_out16 = xn16, p.ln_eps = eps;
+    p.ln_out16 = xn8 ? (void*)xn8 : xn16, p.ln_eps = eps;
+    if (xn8) p.out8 = xn8, p.out8_scale = xn_scale, p.out8_mt = (int32_t)cdiv(M, 128);
     p.ln_w = ln_w[0], p.ln_b = ln_b[0], p.ln_w_s1 = ln_w[1], p.ln_b_s1 = ln_b[1], p.ln_w_s2 = ln_w[2], p.ln_b_s2 = ln_b[2];
     const size_t row_tiles = (size_t)seg_row_tiles<352>(M, seg1, seg2);
     // (an arrival counter advances by N / 256 per launch and must start a launch at a multiple of that: one per N)
     p.ln_stats = (unsigned long long*)site_buf(ctx, "op.ln.stats", row_tiles * (size_t)(N / 256) * 352 * 8);
     p.ln_count = (unsigned*)site_buf(ctx, "op.ln.count." + std::to_string(N), row_tiles * 64);
     gemm_launch(p, A_PLAIN, EPI_RESID_SCALE, ctx->dtype, ctx->stream, 10);
+}
+}  // namespace
+
+int32_t me_op_linear_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
+                                        int32_t seg2, const void* const W16[3], const float* const bias[3],
+                                        const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
+                                        float eps, float* x32, void* xn16) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(xn16, ME_ERR_BAD_ARG, "me_op_linear_residual_layernorm: null pointer");
+    linear_residual_layernorm_impl(ctx, "me_op_linear_residual_layernorm", M, N, K, A16, seg1, seg2, W16, bias, gamma, ln_w, ln_b, eps,
+                                   x32, xn16, nullptr, nullptr);
+    ME_API_END(ctx)
+}
+
+int32_t me_op_linear_residual_layernorm_fp8(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1,
+                                            int32_t seg2, const void* const W16[3], const float* const bias[3],
+                                            const float* const gamma[3], const float* const ln_w[3], const float* const ln_b[3],
+                                            float eps, float* x32, uint8_t* xn8, uint8_t* xn_scale) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(xn8 && xn_scale, ME_ERR_BAD_ARG, "me_op_linear_residual_layernorm_fp8: null pointer");
+    linear_residual_layernorm_impl(ctx, "me_op_linear_residual_layernorm_fp8", M, N, K, A16, seg1, seg2, W16, bias, gamma, ln_w, ln_b,
+                                   eps, x32, nullptr, xn8, xn_scale);
     ME_API_END(ctx)
 }
 

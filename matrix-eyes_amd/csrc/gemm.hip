@@ -191,6 +191,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  ME_ERR_BAD_ARG, "gemm: the fused LayerNorm takes the 352-row tile's residual epilogue with N in {256, 512, 1024}");
         ME_CHECK(p.seg1 == 0 || (p.ln_w_s1 && p.ln_b_s1 && (p.seg2 == 0 || (p.ln_w_s2 && p.ln_b_s2))), ME_ERR_BAD_ARG,
                  "gemm: a row segment without LayerNorm weights");
+        // out8 beside ln_out16: the normalised rows leave as MX fp8 + activation-layout scales instead of 16-bit
+        if (p.out8)
+            ME_CHECK(p.out8_scale && (int64_t)p.out8_mt * 128 >= p.M, ME_ERR_BAD_ARG,
+                     "gemm: the fused LayerNorm's fp8 output needs its block scales (%d tiles of 128 rows for %d rows)", p.out8_mt, p.M);
     }
     if (p.qcols)
         ME_CHECK(epi == EPI_STORE && p.qcols % 64 == 0 && p.qcols <= p.N && p.out16 && !p.out32 && p.act == ACT_NONE &&
@@ -236,6 +240,12 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);
     }
     static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
+    static const bool log_launches = getenv("ME_LOG_LAUNCH") != nullptr;  // one line per launch: which shape a trace row is
+    if (log_launches)
+        fprintf(stderr, "gemm_launch %s %s M=%d N=%d K=%d k=%dx%d/s%d cfg=%s res32=%d out32=%d out16=%d border=%d lo=%d hi2=%d ln=%d\n",
+                amode == A_PLAIN ? "plain" : "conv", kEpi[epi], p.M, p.N, p.K, p.KH, p.KW, p.stride, gemm_config_name(cfg),
+                p.res32 != nullptr, p.out32 != nullptr, p.out16 != nullptr, p.out16_border, (int)p.lo_off16, (int)p.hi2_off16,
+                p.ln_out16 != nullptr);
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +
                        (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg)) + "," +

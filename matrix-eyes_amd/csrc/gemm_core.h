@@ -1003,7 +1003,58 @@ __device__ __forceinline__ void resid_ln_epilogue(const GemmParams& p, f32x4 (&a
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // ---- the normalised rows
+    // ---- the normalised rows, as the next GEMM's MX fp8 operand (GemmParams::out8 beside ln_out16: ME_DTYPE_FP8 contexts,
+    // where the projection runs on this 16-bit tile and fc1 on the scaled fp8 MFMA): a lane's 8 columns are a quarter
+    // of a 32-column MX block, the four lanes of a quad share its scale (layernorm_fp8_kernel's arithmetic: block
+    // maximum -> e8m0 byte -> e4m3 elements); the two rows a lane holds per pass leave as ONE 16-byte store per lane
+    // pair (the even lane stores the first row's 16 columns, the odd lane the second row's), scales as bytes in the
+    // activation layout (mx_fp8.h a_scale_index)
+    if (p.out8) {
+        const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(uniform_ptr((const char*)(p.out8 + (int64_t)mw * p.N + n0 + wn * TN))), 0, 0x7fffffff, 0x00020000);
+        const bool odd = (gc & 1) != 0;
+        unsigned cur8 = (unsigned)(r0 + (odd ? RPI : 0)) * (unsigned)p.N + (unsigned)(gc & ~1) * 8u;
+        int left8 = rows_left - (odd ? RPI : 0);
+        int row8 = mw + r0;            // global row of this lane's first unit
+        int left_s = rows_left;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            asm volatile("" : "+v"(cur8), "+v"(left8), "+v"(row8), "+v"(left_s));
+            uint2 q[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int rt = pass * ROWS + it * RPI;
+                const float2 ms = fin[wm * TM + rt + r0];
+                float o[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 x = ME_XS(pass, it, h);
+                    const float4 w4 = cg[h], b4 = cb[h];
+                    o[4 * h + 0] = (x[0] - ms.x) * ms.y * w4.x + b4.x, o[4 * h + 1] = (x[1] - ms.x) * ms.y * w4.y + b4.y;
+                    o[4 * h + 2] = (x[2] - ms.x) * ms.y * w4.z + b4.z, o[4 * h + 3] = (x[3] - ms.x) * ms.y * w4.w + b4.w;
+                }
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(o[e]));
+                amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0xB1, 0xF, 0xF, true)));
+                amax = fmaxf(amax, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(amax), 0x4E, 0xF, 0xF, true)));
+                const unsigned sb = mx_scale_byte(amax);
+                const float inv = mx_inv_scale(sb);
+                q[it].x = pack_fp8x4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+                q[it].y = pack_fp8x4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+                if ((gc & 3) == 0 && left_s > it * RPI)
+                    p.out8_scale[a_scale_index(row8 + it * RPI, n >> 5, p.out8_mt)] = (uint8_t)sb;
+            }
+            const uint2 send = odd ? q[0] : q[1];
+            uint2 recv;
+            recv.x = __builtin_amdgcn_update_dpp(0, send.x, 0xB1, 0xF, 0xF, true);
+            recv.y = __builtin_amdgcn_update_dpp(0, send.y, 0xB1, 0xF, 0xF, true);
+            const u32x4v ov = odd ? u32x4v{recv.x, recv.y, q[1].x, q[1].y} : u32x4v{q[0].x, q[0].y, recv.x, recv.y};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, r8, left8 > 0 ? cur8 : kOut, 0, 0);
+            cur8 += (unsigned)ROWS * (unsigned)p.N, left8 -= ROWS, row8 += ROWS, left_s -= ROWS;
+        }
+        return;
+    }
     const int64_t wave_el16 = (int64_t)mw * p.N + n0 + wn * TN;
     const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(uniform_ptr((const char*)((T*)p.ln_out16 + wave_el16))), 0, 0x7fffffff, 0x00020000);

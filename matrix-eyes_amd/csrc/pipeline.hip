@@ -286,6 +286,7 @@ struct MergedVit {
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
     bool xn_is_norm1 = false;  // xn already holds norm1 of the block about to run (written by the block before)
+    bool xn_is_norm2_fp8 = false;  // fp8 contexts: xn / xn_s hold norm2 as MX fp8 (written by the projection's epilogue)
     float* fin32 = nullptr;
     // ME_DTYPE_FP8: xn and hid hold e4m3 bytes, with their block scales (activation layout, Rtot / 128 tiles)
     uint8_t *xn_s = nullptr, *hid_s = nullptr, *att8 = nullptr, *att_s = nullptr;
@@ -444,12 +445,12 @@ struct MergedVit {
         static const bool tall = !(getenv("ME_GEMM_TALL") && atoi(getenv("ME_GEMM_TALL")) == 0);
         static const bool pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const int C = ctx->C();
-        return enabled && tall && !pp192 && !ctx->fp8 && (C == 256 || C == 512 || C == 1024);
+        return enabled && tall && !pp192 && (C == 256 || C == 512 || C == 1024);
     }
     // returns true when xn holds LayerNorm(ln) of the updated rows
     bool resid_all(const char* A, int K, const void* w0, const float* bb0, const float* g0, const void* w1,
                    const float* bb1, const float* g1, const void* w2, const float* bb2, const float* g2,
-                   const LnSet* ln = nullptr) {
+                   const LnSet* ln = nullptr, bool ln_fp8 = false /* xn / xn_s as the MX fp8 operand of the next GEMM */) {
         const int C = ctx->C();
         GemmParams p = base_params();
         p.M = (int)Rtot, p.N = C, p.K = K, p.A = A, p.lda = K, p.W = w0, p.bias = bb0, p.gamma = g0;
@@ -464,9 +465,10 @@ struct MergedVit {
         static const bool use_pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const bool pp = C >= 256 && K >= 128;
         const bool pp192 = pp && K <= 1024 && use_pp192 && seg1 % 192 == 0 && seg2 % 192 == 0;
-        if (ln && pp && ln_fusable()) {
+        if (ln && pp && ln_fusable() && (ln_fp8 || !ctx->fp8)) {
             const size_t row_tiles = (size_t)seg_row_tiles<352>((int)Rtot, (int)seg1, (int)seg2);
             p.ln_out16 = xn, p.ln_eps = ctx->cfg.ln_eps;
+            if (ln_fp8) p.out8 = (uint8_t*)xn, p.out8_scale = xn_s, p.out8_mt = (int)(Rtot / 128);
             p.ln_w = ln->w0, p.ln_b = ln->b0, p.ln_w_s1 = ln->w1, p.ln_b_s1 = ln->b1, p.ln_w_s2 = ln->w2, p.ln_b_s2 = ln->b2;
             p.ln_stats = (unsigned long long*)site_buf(ctx, "vitm.ln.stats", row_tiles * (size_t)(C / 256) * 352 * 8);
             p.ln_count = (unsigned*)site_buf(ctx, "vitm.ln.count", row_tiles * 64);   // zero when allocated, never reset
@@ -544,11 +546,16 @@ struct MergedVit {
                 gemm8(att8, att_s, C, C, b0, b1, b2, 3);
             } else {
                 attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
-                resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b, b2.ls1);
+                // the 16-bit projection's residual epilogue writes norm2 as fc1's MX fp8 operand (gemm_core.h resid_ln_epilogue)
+                const LnSet ln2{b0.ln2_w, b0.ln2_b, b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b};
+                xn_is_norm2_fp8 = resid_all(att, C, b0.proj_w, b0.proj_b, b0.ls1, b1.proj_w, b1.proj_b, b1.ls1, b2.proj_w, b2.proj_b,
+                                            b2.ls1, f18 ? &ln2 : nullptr, true);
             }
             set_ln(b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b);
             if (f18) {
-                layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                if (!xn_is_norm2_fp8)
+                    layernorm_fp8_launch(tok, b0.ln2_w, b0.ln2_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                xn_is_norm2_fp8 = false;
                 gemm8(xn, xn_s, C, 4 * C, b0, b1, b2, 1, !f28);
             } else {
                 layernorm_launch(tok, b0.ln2_w, b0.ln2_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);

@@ -393,3 +393,71 @@ def test_attention_writes_the_projection_operand_itself(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape", [(352, 256, 128, 0, 0), (1000, 1024, 256, 0, 0), (1536, 512, 128, 512, 1024),
+                                   (2300, 1024, 1024, 768, 0)])
+def test_linear_residual_layernorm_fp8_fused(shape):
+    """ME_DTYPE_FP8 contexts: the 16-bit projection's residual epilogue writes norm2 as fc1's MX fp8 operand
+    (gemm_core.h resid_ln_epilogue, GemmParams::out8).  x32 is bit for bit the plain residual launch's; the bytes and
+    scales are what me_op_layernorm_fp8 gives on those x32 rows, up to the last bit of a few elements (the two sum a
+    row's statistics in a different order); dequantised they sit within half an e4m3 step of an fp64 LayerNorm; rows
+    behind M are not written."""
+    M, N, K, seg1, seg2 = shape
+    ctx = ctx_for("tiny", "f16")
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).half().cuda()
+    ws = [(torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda() for _ in range(3)]
+    bs = [torch.randn(N, generator=g).cuda() for _ in range(3)]
+    gs = [(0.05 + 0.15 * torch.rand(N, generator=g)).cuda() for _ in range(3)]
+    lw = [(1.0 + 0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    lb = [(0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    x0 = torch.randn(M, N, generator=g) * 2.0
+    x0[:, 7] += 40.0
+    x0[::3] *= 10.0
+    x0 = x0.cuda()
+    plain, fused = x0.clone(), x0.clone()
+    mt = (M + 127) // 128
+    xn8 = torch.full((M + 1, N), 0x55, dtype=torch.uint8, device="cuda")       # a guard row behind the output
+    xs = torch.zeros(mt * 128 * N // 32, dtype=torch.uint8, device="cuda")
+    eps = 1e-5
+    torch.cuda.synchronize()
+    ctx._check(ctx.lib.me_op_linear_segments(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), None, ptr(plain), 0, 10))
+    ctx._check(ctx.lib.me_op_linear_residual_layernorm_fp8(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), arr(lw),
+                                                           arr(lb), eps, ptr(fused), ptr(xn8), ptr(xs)))
+    ctx.synchronize()
+    assert ctx.status_flags() == 0
+    assert torch.equal(fused, plain)
+    assert bool((xn8[M] == 0x55).all())
+    bounds = [0, seg1 if seg1 else M, (seg2 if seg2 else M) if seg1 else M, M]
+    ref = torch.empty(M, N, dtype=torch.float64)
+    xd = fused.double().cpu()
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi > lo:
+            ref[lo:hi] = F.layer_norm(xd[lo:hi], (N,), lw[i].double().cpu(), lb[i].double().cpu(), eps)
+    sb = _read_scales(ctx, xs, M, N, 0)
+    diff = (sb.int() - _scale_bytes(ref.float().abs().reshape(M, N // 32, 32).amax(2)).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
+    got = _dequant(xn8[:M].cpu().view(E4M3), sb)
+    blockmax = ref.abs().reshape(M, N // 32, 32).amax(2, keepdim=True).expand(-1, -1, 32).reshape(M, N)
+    assert float(((got - ref).abs() / blockmax).max()) <= 2.0 ** -4 * 1.01
+    # the stand-alone LayerNorm -> fp8 kernel on the same rows (one weight set: no segments)
+    if seg1 == 0:
+        y8 = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+        ys = torch.zeros_like(xs)
+        ctx._check(ctx.lib.me_op_layernorm_fp8(ctx.handle, ptr(fused), ptr(lw[0]), ptr(lb[0]), ptr(y8), ptr(ys), M, N, eps))
+        ctx.synchronize()
+        assert float((ys != xs).float().mean()) < 1e-3
+        assert float((y8 != xn8[:M]).float().mean()) < 2e-3
+    # again from the same input: the same bytes
+    again = x0.clone()
+    xn8b = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+    xsb = torch.zeros_like(xs)
+    torch.cuda.synchronize()
+    ctx._check(ctx.lib.me_op_linear_residual_layernorm_fp8(ctx.handle, M, N, K, ptr(a), seg1, seg2, arr(ws), arr(bs), arr(gs), arr(lw),
+                                                           arr(lb), eps, ptr(again), ptr(xn8b), ptr(xsb)))
+    ctx.synchronize()
+    assert torch.equal(again, fused) and torch.equal(xn8b, xn8[:M]) and torch.equal(xsb, xs)
+    assert ctx.status_flags() == 0
