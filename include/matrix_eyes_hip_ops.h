@@ -49,6 +49,13 @@ int32_t me_op_conv2d(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32
                      const void* w16, int32_t Cout, int32_t k, int32_t stride, const float* bias,
                      const float* res32, const float* res32b, float* out32, void* out16,
                      int32_t border16, int32_t act, int32_t act_both, int32_t tile_cfg);
+/* The depth head's last layers (mod.rs:83-94,329-362): relu(conv3x3(in, w16 [Cmid][9][Cin]) + bias) . w2 + b2, ReLU,
+   / f_norm[b] (null: not divided), clamp -> out32 [B][H][W].  in16b: zero-bordered NHWC.  tile_cfg -1: the halo kernel
+   (csrc/head_conv.hip) where the shape is the model's (Cin 128, Cmid 32, H % 12 == 0, W % 16 == 0), the implicit-GEMM
+   tile elsewhere; >= 0: the implicit-GEMM tile. */
+int32_t me_op_head_final(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w16,
+                         int32_t Cmid, const float* bias, const float* w2, const float* b2, const float* f_norm,
+                         float clamp_lo, float clamp_hi, float* out32, int32_t tile_cfg);
 /* ConvTranspose2d(2,2,stride 2): in16 NHWC [B*H*W][Cin]; w16 packed [(dy*2+dx)*Cout + co][Cin];
    out32 [B][2H][2W][Cout] and/or out16 (zero-bordered when border16). */
 int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_t H, int32_t W,

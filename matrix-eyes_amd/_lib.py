@@ -92,6 +92,7 @@ SIGNATURES = {
     "me_op_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
     "me_op_conv2d": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                             _vp, _vp, _i32, _i32, _i32, _i32]),
+    "me_op_head_final": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _i32]),
     "me_op_conv_transpose2x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp,
                                        _i32, _i32]),
     "me_op_quantize_fp8": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),

@@ -902,6 +902,22 @@ int32_t me_op_conv2d(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32
     ME_API_END(ctx)
 }
 
+int32_t me_op_head_final(me_ctx* ctx, const void* in16b, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w16,
+                         int32_t Cmid, const float* bias, const float* w2, const float* b2, const float* f_norm,
+                         float clamp_lo, float clamp_hi, float* out32, int32_t tile_cfg) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(in16b && w16 && bias && w2 && b2 && out32, ME_ERR_BAD_ARG, "me_op_head_final: null pointer");
+    ME_CHECK(B > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cmid > 0 && Cmid <= 32 && Cmid % 4 == 0, ME_ERR_BAD_SHAPE,
+             "me_op_head_final: %d x %d x %d, %d -> %d", B, H, W, Cin, Cmid);
+    GemmParams p = GemmParams();
+    p.M = B * H * W, p.N = Cmid, p.K = 9 * Cin, p.A = in16b;
+    p.in_Hp = H + 2, p.in_Wp = W + 2, p.Cin = Cin, p.out_H = H, p.out_W = W;
+    p.KH = 3, p.KW = 3, p.stride = 1, p.W = w16, p.bias = bias, p.w2 = w2, p.b2 = b2, p.f_norm = f_norm;
+    p.pixels_per_image = H * W, p.out32 = out32, p.clamp_lo = clamp_lo, p.clamp_hi = clamp_hi, p.ldc = Cmid;
+    gemm_launch(p, A_CONV, EPI_HEAD_FINAL, ctx->dtype, ctx->stream, tile_cfg);
+    ME_API_END(ctx)
+}
+
 int32_t me_op_conv_transpose2x2(me_ctx* ctx, const void* in16, int32_t B, int32_t H, int32_t W,
                                 int32_t Cin, const void* w16, int32_t Cout, const float* bias,
                                 float* out32, void* out16, int32_t border16, int32_t tile_cfg) {

@@ -274,6 +274,11 @@ __host__ __device__ __forceinline__ int seg_row_tiles(int M, int seg1, int seg2)
 // dtype: ME_DTYPE_F16 / ME_DTYPE_BF16.  Picks a tile configuration from (M, N, K).
 void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg = -1);
+// The depth head's final 3x3 (128 -> 32) + 1x1 (32 -> 1) on a pixel halo tile with the weights held in registers
+// (head_conv.hip); gemm_launch takes it for EPI_HEAD_FINAL where the shape fits (ME_HEAD_HALO=0: the implicit-GEMM tile)
+bool head_final_halo_fits(const GemmParams& p);
+void head_final_halo_launch(const GemmParams& p, int32_t dtype, hipStream_t stream);
+
 // MX fp8 x fp8 (gemm_fp8.hip): EPI_STORE (f16 out16, or fp8 out8 + scales) / EPI_RESID_SCALE
 void gemm_fp8_launch(const GemmParams& p, EpiKind epi, hipStream_t stream);
 // f16 [rows][K] -> e4m3 + e8m0 scales in the weight (1) or activation (0) scale layout

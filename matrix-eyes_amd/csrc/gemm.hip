@@ -240,6 +240,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  "gemm: row segments %d / %d do not start on %d-row tile boundaries", p.seg1, p.seg2, bm);
     }
     static const char* kEpi[] = {"store", "resid_scale", "patch_embed", "?", "convt", "head_final"};
+    // the head's final layers on a halo tile (head_conv.hip) where the shape is the model's own; force_cfg >= 0 or
+    // ME_HEAD_HALO=0: the implicit-GEMM tile below
+    static const bool head_halo_on = !(getenv("ME_HEAD_HALO") && atoi(getenv("ME_HEAD_HALO")) == 0);
+    const bool head_halo = epi == EPI_HEAD_FINAL && amode == A_CONV && force_cfg < 0 && head_halo_on && head_final_halo_fits(p);
     static const bool log_launches = getenv("ME_LOG_LAUNCH") != nullptr;  // one line per launch: which shape a trace row is
     if (log_launches)
         fprintf(stderr, "gemm_launch %s %s M=%d N=%d K=%d k=%dx%d/s%d cfg=%s res32=%d out32=%d out16=%d border=%d lo=%d hi2=%d ln=%d\n",
@@ -248,9 +252,13 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                 p.ln_out16 != nullptr);
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +
-                       (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg)) + "," +
+                       (head_halo ? "12x16px-x32/8w-halo" : (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg))) + "," +
                        (amode == A_PLAIN ? "plain" : "conv") + "," + kEpi[epi] + ">",
                    2.0 * (p.flop_rows ? p.flop_rows : p.M) * p.N * (p.flop_k ? p.flop_k : p.K), 0.0);
+    if (head_halo) {
+        head_final_halo_launch(p, dtype, stream);
+        return;
+    }
     if (dtype == ME_DTYPE_F16)
         launch_typed<f16>(p, amode, epi, cfg, stream);
     else if (dtype == ME_DTYPE_BF16)

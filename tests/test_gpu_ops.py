@@ -817,3 +817,51 @@ def test_outlier_activations_through_a_residual_conv_unit():
         err = float(((got - xs.double()) - branch).norm() / branch.norm())
         print("RCU branch rel-L2 at scale", scale, err)
         assert torch.isfinite(out32).all() and err < 1.0e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(B=1, H=12, W=16, Cin=128, Cmid=32),                 # one tile of the halo kernel
+    dict(B=2, H=48, W=64, Cin=128, Cmid=32, f_norm=True),    # 2 x 16 tiles, per-image f_norm
+    dict(B=1, H=384, W=400, Cin=128, Cmid=32, f_norm=True),  # 800 tiles: workgroups walk on (double-buffered halo)
+    dict(B=3, H=36, W=48, Cin=128, Cmid=32, clamp=True),
+    dict(B=2, H=24, W=128, Cin=128, Cmid=32, f_norm=True),   # 8 tile columns: one per XCD (the strip walk)
+    dict(B=3, H=132, W=256, Cin=128, Cmid=32),               # strips of two tile columns, 528 tiles
+    dict(B=1, H=20, W=24, Cin=128, Cmid=32),                 # not a multiple of 12 x 16: the implicit-GEMM tile
+    dict(B=1, H=24, W=32, Cin=64, Cmid=32),                  # another channel count: the implicit-GEMM tile
+])
+def test_head_final(dtype, case):
+    """mod.rs:83-94,329-362: conv3x3 (128 -> 32) + ReLU + conv1x1 (32 -> 1) + ReLU, / f_norm, clamp in one launch --
+    the halo kernel (csrc/head_conv.hip) where the shape is the model's, the implicit-GEMM tile elsewhere, both against
+    torch on the same 16-bit operands, and against each other where both apply."""
+    ctx = ctx_for("tiny", dtype)
+    B, H, W, Cin, Cmid = (case[n] for n in ("B", "H", "W", "Cin", "Cmid"))
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cmid, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cmid, generator=g) * 0.3
+    w2 = torch.randn(Cmid, generator=g) / math.sqrt(Cmid)
+    b2 = torch.tensor([0.4])
+    f_norm = (0.5 + torch.rand(B, generator=g)) if case.get("f_norm") else None
+    lo, hi = (0.2, 1.5) if case.get("clamp") else (-float("inf"), float("inf"))
+    xb, w16 = bordered(x, dtype), dev16(pack_conv(w), dtype)
+    bias_d, w2_d, b2_d = bias.cuda(), w2.cuda(), b2.cuda()
+    fn_d = f_norm.cuda() if f_norm is not None else None
+    outs = {}
+    for cfg in (-1, 2):
+        out = torch.full((B * H * W + 16,), -7.0, device="cuda")
+        _check(ctx, ctx.lib.me_op_head_final(ctx.handle, ptr(xb), B, H, W, Cin, ptr(w16), Cmid, ptr(bias_d), ptr(w2_d), ptr(b2_d),
+                                             ptr(fn_d), lo, hi, ptr(out), cfg))
+        ctx.synchronize()
+        assert bool((out[B * H * W:] == -7.0).all())
+        outs[cfg] = out[:B * H * W].cpu().double().reshape(B, H, W)
+    x16 = xb[:, 1:H + 1, 1:W + 1, :].permute(0, 3, 1, 2).double().cpu()
+    mid = F.relu(F.conv2d(x16, dev16(w, dtype).double().cpu(), bias.double(), padding=1))
+    ref = F.relu((mid * w2.double().view(1, Cmid, 1, 1)).sum(1) + b2.double())
+    if f_norm is not None:
+        ref = ref / f_norm.double().view(B, 1, 1)
+    ref = ref.clamp(lo, hi)
+    scale = float(ref.abs().max())
+    for cfg, got in outs.items():
+        assert float((got - ref).abs().max()) < 2e-5 * scale, (cfg, float((got - ref).abs().max()), scale)
+    assert float((outs[-1] - outs[2]).abs().max()) < 2e-5 * scale
