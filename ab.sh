@@ -1,14 +1,7 @@
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r4prof
-mkdir -p $O
-export TMPDIR=/tmp
-cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1; echo "rc=$?"
-cd $GRAFT_REPO_ROOT
-grep '^{"metric"' $O/bench_under_rocprof.log > $O/bench_under_rocprof_f16.json
-cp $(find $O/tr -name "*kernel_stats.csv" | head -1) $O/kernel_stats_f16.csv
-f=$(find $O/tr -name "*kernel_trace.csv" | head -1)
-python3 tools/step_timeline.py $f 4 > $O/step_timeline.txt 2>&1
-rm -rf $O/tr
-head -12 $O/kernel_stats_f16.csv | cut -c1-160
-head -4 $O/step_timeline.txt
+mkdir -p gpurun_out/r4trace
+for lim in 256 128 64; do
+echo "ME_GEMM_GRID_LIMIT=$lim"
+BW_PROBE_AUTO=1 ME_GEMM_GRID_LIMIT=$lim timeout -k 10 200 python tools/bw_bound_probe.py 2>&1 | grep -v "amdgpu.ids\|ME_STAGGER"
+done > gpurun_out/r4trace/grid_limit.txt
+cat gpurun_out/r4trace/grid_limit.txt
