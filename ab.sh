@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4trace
-for lim in 256 128 64; do
-echo "ME_GEMM_GRID_LIMIT=$lim"
-BW_PROBE_AUTO=1 ME_GEMM_GRID_LIMIT=$lim timeout -k 10 200 python tools/bw_bound_probe.py 2>&1 | grep -v "amdgpu.ids\|ME_STAGGER"
-done > gpurun_out/r4trace/grid_limit.txt
-cat gpurun_out/r4trace/grid_limit.txt
+O=gpurun_out/r4final5
+mkdir -p $O
+timeout -k 10 300 python bench.py --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_f16_batch8.json 2>/dev/null; echo "B rc=$?"
+timeout -k 10 300 python bench.py --dtype fp8 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_fp8_batch8.json 2>/dev/null; echo "C2 rc=$?"
+timeout -k 10 300 python bench.py --chain --no-cpu-baseline > $O/bench_chain.json 2>/dev/null; echo "D1 rc=$?"
+timeout -k 10 300 python bench.py --chain --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_chain_batch8.json 2>/dev/null; echo "D2 rc=$?"
+timeout -k 10 300 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2>/dev/null; echo "E rc=$?"
+for f in bench_f16_batch8 bench_fp8_batch8 bench_chain bench_chain_batch8 bench_graph; do python -c "import json,sys; d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); r=d.get('roofline',{}); print('$f', d['value'], d['ms_per_step'], r.get('frac'), r.get('traffic_source'))"; done

@@ -266,15 +266,14 @@ bool head_final_halo_fits(const GemmParams& p) {
 
 void head_final_halo_launch(const GemmParams& p, int32_t dtype, hipStream_t stream) {
     ME_CHECK(head_final_halo_fits(p), ME_ERR_BAD_SHAPE, "head: the halo kernel takes 3x3 / 128 -> 32 on maps of 12 x 16 pixel multiples");
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, cus = 0;
-        ME_HIP(hipGetDevice(&dev));
-        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static PerDeviceOnce once;  // per device: the LDS the kernel asks for, and how many workgroups are resident (one per CU)
+    const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)head_halo_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_SMEM));
         ME_HIP(hipFuncSetAttribute((const void*)head_halo_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_SMEM));
-        resident = cus > 0 ? cus : 256;
-    }
+        int cus = 0;
+        ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        return cus > 0 ? cus : 256;
+    });
     const int ntiles = (p.M / (p.out_H * p.out_W)) * (p.out_H / HEAD_TH) * (p.out_W / 16);
     int grid = ntiles < resident ? ntiles : resident;
     if (p.grid_cap >= 8 && grid > p.grid_cap) grid = p.grid_cap;
