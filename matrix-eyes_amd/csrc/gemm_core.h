@@ -309,13 +309,23 @@ constexpr int epi_mi_chunk(int MI, int TN, int NW, int main_bytes) {
 // depends only on n (bias, gamma) is loaded once per lane, the pixel coordinates of bordered / pixel-
 // shuffled outputs walk with the row, f32 results leave as two 16-byte stores and 16-bit results as
 // ONE 16-byte store (8-byte stores ran the qkv epilogue at 2.9 TB/s, 16-byte ones at 7 TB/s).
+#ifndef ME_EPI_PRE
+#define ME_EPI_PRE 1
+#endif
+// epilogue_granule<EPI_STORE, MODE >= kEpiConst>: which options of the launch are compiled in
+constexpr int kEpiConst = 16, kEpiRes = 1, kEpiOut32 = 2, kEpiOut16 = 4, kEpiBorder = 8, kEpiLo = 32, kEpiHi2 = 64;
 struct EpiLane {
     float4 bias[2], gamma[2];  // per-lane constants for columns n..n+3 and n+4..n+7
     int q, co;                 // EPI_CONVT: n = q * Cout + co
+    int add32, add16;          // EPI_CONVT: element offsets of (sub-pixel q, channel co) from output pixel (2y, 2x)
 };
 struct EpiRow {
     int m;        // output row
     int b, y, x;  // pixel of that row when rows are pixels of [B][out_H][out_W]
+    // EPI_CONVT: element offsets of output pixel (b, 2y, 2x) in out32 and out16 (the bordered layout included), walked with
+    // the row -- worked out per granule from (b, y, x) they were two 64-bit products per row: the head's ConvTranspose took
+    // 239 us where the same GEMM with a row-major store takes 185
+    int64_t o32, o16;
 };
 
 // amax16: running largest magnitude this lane has rounded to an f16 operand (the overflow guard of common.h;
@@ -364,13 +374,14 @@ __device__ __forceinline__ void store_16bit_lo(T* dst, const float (&a)[8], bool
 // MODE 3: bias (+ GELU) then quantised to MX fp8 (the fp8 GEMM's fc1 epilogue, mx_fp8.h)
 // MODE: 0 = every option checked at run time; 1 / 2 = the ViT fast paths of EPI_STORE (16-bit output
 // only, bias, no residual, no border; 1: no activation (qkv), 2: GELU (fc1)) with the branches gone
+// pre: the granule's two residual vectors, already loaded (compiled-in residual modes: the pass's loads go out together)
 template <typename T, int EPI, int MODE>
 __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiRow& r, int n,
                                                  const EpiLane& lc, const f32x4 (&v)[2], bool hi_ok,
-                                                 float& amax16) {
+                                                 float& amax16, const float4* pre = nullptr) {
     const int m = r.m;
     float a[8];  // values for the 16-bit copy
-    if constexpr (EPI == EPI_STORE && MODE != 0) {
+    if constexpr (EPI == EPI_STORE && MODE != 0 && MODE < kEpiConst) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
@@ -389,42 +400,63 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             store_16bit<T>((T*)p.out16 + (int64_t)m * p.ldc + n, a, hi_ok);
         }
     } else if constexpr (EPI == EPI_STORE) {
+        // MODE 0: every option of the launch checked at run time, per granule.  MODE >= 16 (kEpiConst | flag bits): the
+        // option combinations the convolutions of the model launch, as compile-time constants, the activation without a
+        // branch (a lower bound of 0 or -inf) -- see EPI_CONVT below for what the run-time checks cost a store-heavy launch.
+        constexpr bool CF = MODE >= kEpiConst;
+        const bool f_res = CF ? (MODE & kEpiRes) != 0 : p.res32 != nullptr;
+        const bool f_resb = CF ? false : p.res32b != nullptr;
+        const bool f_o32 = CF ? (MODE & kEpiOut32) != 0 : p.out32 != nullptr;
+        const bool f_o16 = CF ? (MODE & kEpiOut16) != 0 : p.out16 != nullptr;
+        const bool f_border = CF ? (MODE & kEpiBorder) != 0 : p.out16_border != 0;
+        const bool f_lo = CF ? (MODE & kEpiLo) != 0 : p.lo_off16 != 0;
+        const bool f_hi2 = CF ? (MODE & kEpiHi2) != 0 : p.hi2_off16 != 0;
+        // CF: ReLU (or none) as max(x, bound): bound16 for the 16-bit copy, bound32 for the f32 output (act16_only: unclamped)
+        const float bound16 = p.act == ACT_RELU ? 0.f : -INFINITY;
+        const float bound32 = (p.act == ACT_RELU && !p.act16_only) ? 0.f : -INFINITY;
         const int64_t row32 = (int64_t)m * p.ldc;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && !hi_ok) break;
             float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
-            if (p.res32) {
-                const float4 r4 = *reinterpret_cast<const float4*>(p.res32 + row32 + n + 4 * h);
+            if (f_res) {
+                const float4 r4 = (CF && ME_EPI_PRE) ? pre[h] : *reinterpret_cast<const float4*>(p.res32 + row32 + n + 4 * h);
                 x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
             }
-            if (p.res32b) {
+            if (f_resb) {
                 const float4 r4 = *reinterpret_cast<const float4*>(p.res32b + row32 + n + 4 * h);
                 x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
             }
             float a0 = x0, a1 = x1, a2 = x2, a3 = x3;
-            if (p.act == ACT_GELU) {
-                const f32x4 g = gelu_erf4(f32x4{x0, x1, x2, x3});
-                a0 = g[0], a1 = g[1], a2 = g[2], a3 = g[3];
-            } else if (p.act == ACT_RELU) {
-                a0 = fmaxf(x0, 0.f), a1 = fmaxf(x1, 0.f), a2 = fmaxf(x2, 0.f), a3 = fmaxf(x3, 0.f);
+            if constexpr (CF) {
+                a0 = fmaxf(x0, bound16), a1 = fmaxf(x1, bound16), a2 = fmaxf(x2, bound16), a3 = fmaxf(x3, bound16);
+                if (f_o32)
+                    *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
+                        make_float4(fmaxf(x0, bound32), fmaxf(x1, bound32), fmaxf(x2, bound32), fmaxf(x3, bound32));
+            } else {
+                if (p.act == ACT_GELU) {
+                    const f32x4 g = gelu_erf4(f32x4{x0, x1, x2, x3});
+                    a0 = g[0], a1 = g[1], a2 = g[2], a3 = g[3];
+                } else if (p.act == ACT_RELU) {
+                    a0 = fmaxf(x0, 0.f), a1 = fmaxf(x1, 0.f), a2 = fmaxf(x2, 0.f), a3 = fmaxf(x3, 0.f);
+                }
+                if (f_o32)
+                    *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
+                        p.act16_only ? make_float4(x0, x1, x2, x3) : make_float4(a0, a1, a2, a3);
             }
-            if (p.out32)
-                *reinterpret_cast<float4*>(p.out32 + row32 + n + 4 * h) =
-                    p.act16_only ? make_float4(x0, x1, x2, x3) : make_float4(a0, a1, a2, a3);
             a[4 * h] = a0, a[4 * h + 1] = a1, a[4 * h + 2] = a2, a[4 * h + 3] = a3;
         }
-        if (p.out16) {
+        if (f_o16) {
             const int64_t ld16 = p.ldc16 ? p.ldc16 : p.ldc;
             const int64_t row16 =
-                p.out16_border
+                f_border
                     ? (((int64_t)r.b * (p.out_H + 2) + r.y + 1) * (p.out_W + 2) + r.x + 1) * ld16
                     : (int64_t)m * ld16;
             track_amax16<T>(amax16, a, hi_ok);
             store_16bit<T>((T*)p.out16 + row16 + n, a, hi_ok);
-            if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + row16 + n + p.lo_off16, a, hi_ok);
-            if (p.hi2_off16) store_16bit<T>((T*)p.out16 + row16 + n + p.hi2_off16, a, hi_ok);
+            if (f_lo) store_16bit_lo<T>((T*)p.out16 + row16 + n + p.lo_off16, a, hi_ok);
+            if (f_hi2) store_16bit<T>((T*)p.out16 + row16 + n + p.hi2_off16, a, hi_ok);
         }
     } else if constexpr (EPI == EPI_RESID_SCALE) {
         const int64_t row32 = (int64_t)m * p.ldc;
@@ -453,30 +485,32 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                             v[h][2] + lc.bias[h].z + e4.z, v[h][3] + lc.bias[h].w + e4.w);
         }
     } else if constexpr (EPI == EPI_CONVT) {
-        const int oy = 2 * r.y + (lc.q >> 1), ox = 2 * r.x + (lc.q & 1);
-        const int oH = 2 * p.out_H, oW = 2 * p.out_W;
+        // MODE 0: every option checked at run time, per granule.  MODE 4 .. 7: the combinations the model launches, as
+        // compile-time constants -- 4: 16-bit output, 5: f32 output, 6: both, 7: 16-bit [hi | lo]; no ReLU.  With the
+        // checks in the granule (uniform branches, but branches: the granules' LDS reads and stores cannot be moved
+        // across them) a store-heavy launch pays for them: the head's ConvTranspose 231 us, the same GEMM with a
+        // row-major store through the run-time path 261 us, through the constant path 182 us.
+        const bool w32 = MODE == 0 ? p.out32 != nullptr : (MODE == 5 || MODE == 6);
+        const bool w16 = MODE == 0 ? p.out16 != nullptr : (MODE == 4 || MODE == 6 || MODE == 7);
+        const bool relu = MODE == 0 ? p.act == ACT_RELU : false;
+        const bool lo = MODE == 0 ? p.lo_off16 != 0 : MODE == 7;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && !hi_ok) break;
             const float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             const float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
-            if (p.out32) {
-                const int64_t o = (((int64_t)r.b * oH + oy) * oW + ox) * p.ldc + lc.co + 4 * h;
+            if (w32) {
+                const int64_t o = r.o32 + lc.add32 + 4 * h;
                 *reinterpret_cast<float4*>(p.out32 + o) = make_float4(x0, x1, x2, x3);
             }
-            const bool relu = p.act == ACT_RELU;
             a[4 * h] = relu ? fmaxf(x0, 0.f) : x0, a[4 * h + 1] = relu ? fmaxf(x1, 0.f) : x1;
             a[4 * h + 2] = relu ? fmaxf(x2, 0.f) : x2, a[4 * h + 3] = relu ? fmaxf(x3, 0.f) : x3;
         }
-        if (p.out16) {
-            const int64_t ld16 = p.ldc16 ? p.ldc16 : p.ldc;
-            const int64_t o =
-                p.out16_border
-                    ? ((((int64_t)r.b * (oH + 2) + oy + 1) * (oW + 2) + ox + 1) * ld16 + lc.co)
-                    : ((((int64_t)r.b * oH + oy) * oW + ox) * ld16 + lc.co);
+        if (w16) {
+            const int64_t o = r.o16 + lc.add16;
             track_amax16<T>(amax16, a, hi_ok);
             store_16bit<T>((T*)p.out16 + o, a, hi_ok);
-            if (p.lo_off16) store_16bit_lo<T>((T*)p.out16 + o + p.lo_off16, a, hi_ok);
+            if (lo) store_16bit_lo<T>((T*)p.out16 + o + p.lo_off16, a, hi_ok);
         }
     }
 }
@@ -554,10 +588,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         const bool n_ok = n < p.N, hi_ok = n + 4 < p.N;
         EpiLane lc;
         lc.bias[0] = lc.bias[1] = lc.gamma[0] = lc.gamma[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        lc.q = 0, lc.co = n;
+        lc.q = 0, lc.co = n, lc.add32 = 0, lc.add16 = 0;
+        // EPI_CONVT: strides of the output maps (elements) -- out32 [B][2H][2W][ldc], out16 [B][2H (+2)][2W (+2)][ld16]
+        [[maybe_unused]] const int ct_ld16 = (int)(p.ldc16 ? p.ldc16 : p.ldc);
+        [[maybe_unused]] const int ct_w16 = 2 * p.out_W + (p.out16_border ? 2 : 0);
         if constexpr (EPI == EPI_CONVT) {
             lc.q = n / p.Cout;
             lc.co = n - lc.q * p.Cout;
+            lc.add32 = ((lc.q >> 1) * 2 * p.out_W + (lc.q & 1)) * p.ldc + lc.co;
+            lc.add16 = ((lc.q >> 1) * ct_w16 + (lc.q & 1)) * ct_ld16 + lc.co;
         }
         if (n_ok) {
             const int seg = row_segment(p, m0);
@@ -592,6 +631,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         EpiRow row;
         row.m = m0 + wm * TM + r0;
         row.b = row.y = row.x = 0;
+        row.o32 = row.o16 = 0;
         [[maybe_unused]] int t2_b = 0, t2_y0 = 0, t2_x0 = 0, t2_row = wm * TM + r0;  // TILE2D: tile origin, row in tile
         if constexpr (TILE2D) {
             const int tx = p.out_W >> 4, ty = p.out_H / TILE_H;  // tiles of TILE_H rows x 16 columns of pixels
@@ -610,6 +650,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             const int rem = mm - row.b * ppi;
             row.y = rem / p.out_W;
             row.x = rem - row.y * p.out_W;
+            if constexpr (EPI == EPI_CONVT) {
+                const int oH = 2 * p.out_H, oW = 2 * p.out_W, bd = p.out16_border ? 1 : 0;
+                row.o32 = (((int64_t)row.b * oH + 2 * row.y) * oW + 2 * row.x) * p.ldc;
+                row.o16 = (((int64_t)row.b * (oH + 2 * bd) + 2 * row.y + bd) * ct_w16 + 2 * row.x + bd) * ct_ld16;
+            }
         }
         float amax16 = 0.f;
         auto run = [&](auto mode_tag) {
@@ -696,13 +741,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                                                   ((((j * 16 + ncol) >> 2) ^ frow) & CMASK) * 16) =
                             acc[pass * MI_CH + i][j];
                 // LDS operations of one wave execute in order: the reads below see the writes above
+                // (the compiled-in modes read their rows back a group of granules at a time, further down: with every
+                // branch gone the scheduler otherwise keeps a whole pass of them in flight beside the residual vectors,
+                // and the 256-register kernels spill)
+                constexpr bool LATE_V = EPI == EPI_STORE && MODE >= kEpiConst;
                 f32x4 v[ITERS][2];
+                if constexpr (!LATE_V) {
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int rr = it * RPI + r0;
-                    const char* src = epi_lds + rr * RS;
-                    v[it][0] = *reinterpret_cast<const f32x4*>(src + (((2 * gc) ^ rr) & CMASK) * 16);
-                    v[it][1] = *reinterpret_cast<const f32x4*>(src + (((2 * gc + 1) ^ rr) & CMASK) * 16);
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int rr = it * RPI + r0;
+                        const char* src = epi_lds + rr * RS;
+                        v[it][0] = *reinterpret_cast<const f32x4*>(src + (((2 * gc) ^ rr) & CMASK) * 16);
+                        v[it][1] = *reinterpret_cast<const f32x4*>(src + (((2 * gc + 1) ^ rr) & CMASK) * 16);
+                    }
                 }
                 if constexpr (MODE == 3) {
                     // fp8 output (M, N multiples of 256: every row and column exists): two rows at a time, so that
@@ -751,9 +802,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     }
                     continue;
                 }
+                // compiled-in residual modes: the residual vectors of PB granules are requested together, before the first of
+                // their stores -- loaded where they are used, each granule's load stays behind the store of the granule before
+                // it (the output may be the residual, for all the compiler knows) and a pass is ITERS memory latencies long.
+                // (A whole pass at once -- 8 registers per granule -- spills in the 256-register kernels.)
+                constexpr bool PRE = ME_EPI_PRE && EPI == EPI_STORE && MODE >= kEpiConst && (MODE & kEpiRes) != 0;
+                constexpr int PB = PRE ? (ITERS % 2 == 0 ? 2 : 1) : 1;
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    if (row.m < Mrows && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16);
+                for (int it0 = 0; it0 < ITERS; it0 += PB) {
+                float4 pre[PB][2];
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        int m_it;
+                        if constexpr (TILE2D) {
+                            const int tr = t2_row + u * RPI;
+                            m_it = (t2_b * p.out_H + t2_y0 + (tr >> 4)) * p.out_W + t2_x0 + (tr & 15);
+                        } else {
+                            m_it = row.m + u * RPI;
+                        }
+                        const bool ok = m_it < Mrows && n_ok;
+                        const float* src = p.res32 + (int64_t)(ok ? m_it : 0) * p.ldc + n;
+                        pre[u][0] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        pre[u][1] = ok && hi_ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if constexpr (LATE_V) {
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        const int rr = (it0 + u) * RPI + r0;
+                        const char* src = epi_lds + rr * RS;
+                        v[it0 + u][0] = *reinterpret_cast<const f32x4*>(src + (((2 * gc) ^ rr) & CMASK) * 16);
+                        v[it0 + u][1] = *reinterpret_cast<const f32x4*>(src + (((2 * gc + 1) ^ rr) & CMASK) * 16);
+                    }
+                    asm volatile("" ::: "memory");  // (keeps the next group's reads behind this group's stores)
+                }
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const int it = it0 + u;
+                    if (row.m < Mrows && n_ok) epilogue_granule<T, EPI, MODE>(p, row, n, lc, v[it], hi_ok, amax16, PRE ? pre[u] : nullptr);
                     if constexpr (TILE2D) {
                         t2_row += RPI;
                         row.y = t2_y0 + (t2_row >> 4), row.x = t2_x0 + (t2_row & 15);
@@ -763,11 +850,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     }
                     if (pix) {
                         row.x += RPI;
+                        if constexpr (EPI == EPI_CONVT) row.o32 += 2 * RPI * p.ldc, row.o16 += 2 * RPI * ct_ld16;
                         while (row.x >= p.out_W) {
                             row.x -= p.out_W;
-                            if (++row.y == p.out_H) row.y = 0, ++row.b;
+                            // one input row down = two output rows down, 2 W output pixels back
+                            if constexpr (EPI == EPI_CONVT)
+                                row.o32 += (int64_t)(2 * p.out_W) * p.ldc, row.o16 += (int64_t)(2 * ct_w16 - 2 * p.out_W) * ct_ld16;
+                            if (++row.y == p.out_H) {
+                                row.y = 0, ++row.b;
+                                if constexpr (EPI == EPI_CONVT)  // the next image's first row: over the two border rows
+                                    if (p.out16_border) row.o16 += (int64_t)(2 * ct_w16) * ct_ld16;
+                            }
                         }
                     }
+                }
                 }
             }
         };
@@ -784,10 +880,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         } else if constexpr (EPI == EPI_STORE) {
             const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias &&
                                 !p.lo_off16 && !p.ldc16;
+            // the convolutions' combinations (no second residual, no GELU): compiled-in options
+            const int mask = (p.res32 ? kEpiRes : 0) | (p.out32 ? kEpiOut32 : 0) | (p.out16 ? kEpiOut16 : 0) |
+                             (p.out16_border ? kEpiBorder : 0) | (p.lo_off16 ? kEpiLo : 0) | (p.hi2_off16 ? kEpiHi2 : 0);
+            // (not in the 352-row tile's kernel, MI == 11: it serves the ViT's qkv / fc1 through modes 1 and 2, and the other
+            // bodies beside them cost it registers -- per-pass scratch reloads inside its store loops)
+            constexpr bool CF_MODES = MI != 11;
+            const bool cf_ok = CF_MODES && !p.res32b && p.act != ACT_GELU && p.bias;
             if (simple && p.act == ACT_NONE)
                 run(std::integral_constant<int, 1>());
             else if (simple && p.act == ACT_GELU)
                 run(std::integral_constant<int, 2>());
+            else if (cf_ok) {
+                if constexpr (CF_MODES) {
+                    if (mask == (kEpiOut16 | kEpiBorder))
+                        run(std::integral_constant<int, kEpiConst | kEpiOut16 | kEpiBorder>());
+                    else if (mask == (kEpiOut32 | kEpiOut16 | kEpiBorder))
+                        run(std::integral_constant<int, kEpiConst | kEpiOut32 | kEpiOut16 | kEpiBorder>());
+                    else if (mask == (kEpiRes | kEpiOut32 | kEpiOut16 | kEpiBorder))
+                        run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut32 | kEpiOut16 | kEpiBorder>());
+                    else if (mask == (kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2))
+                        run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2>());
+                    else if (mask == (kEpiRes | kEpiOut16 | kEpiLo))
+                        run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut16 | kEpiLo>());
+                    else if (mask == kEpiOut16)
+                        run(std::integral_constant<int, kEpiConst | kEpiOut16>());
+                    else if (mask == (kEpiOut16 | kEpiLo))
+                        run(std::integral_constant<int, kEpiConst | kEpiOut16 | kEpiLo>());
+                    else
+                        run(std::integral_constant<int, 0>());
+                }
+            }
+            else
+                run(std::integral_constant<int, 0>());
+        } else if constexpr (EPI == EPI_CONVT) {
+            const bool plain = p.act == ACT_NONE;
+            if (plain && p.out16 && !p.out32 && !p.lo_off16)
+                run(std::integral_constant<int, 4>());
+            else if (plain && p.out32 && !p.out16)
+                run(std::integral_constant<int, 5>());
+            else if (plain && p.out32 && p.out16 && !p.lo_off16)
+                run(std::integral_constant<int, 6>());
+            else if (plain && p.out16 && !p.out32 && p.lo_off16)
+                run(std::integral_constant<int, 7>());
             else
                 run(std::integral_constant<int, 0>());
         } else {

@@ -18,6 +18,7 @@ for H, cin, cout in ((768, 128, 128), (384, 512, 256)):
     out_b = torch.zeros((2 * H + 2) ** 2, cout, dtype=torch.float16, device="cuda")
     out_u = torch.zeros((2 * H) ** 2, cout, dtype=torch.float16, device="cuda")
     calls = {"plain 16-bit store [M][N]": lambda: lib.me_op_linear(h, M, N, K, ptr(x), ptr(w), ptr(bias), ptr(out_plain), None, 0, 0),
+             "plain store, generic epilogue path": lambda: lib.me_op_linear(h, M, N, K, ptr(x), ptr(w), None, ptr(out_plain), None, 0, 0),
              "ConvTranspose, bordered 16-bit": lambda: lib.me_op_conv_transpose2x2(h, ptr(x), 1, H, H, cin, ptr(w), cout, None, None, ptr(out_b), 1, 0),
              "ConvTranspose, unbordered 16-bit": lambda: lib.me_op_conv_transpose2x2(h, ptr(x), 1, H, H, cin, ptr(w), cout, None, None, ptr(out_u), 0, 0)}
     ts = {k: [] for k in calls}
