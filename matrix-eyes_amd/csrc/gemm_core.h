@@ -313,7 +313,7 @@ constexpr int epi_mi_chunk(int MI, int TN, int NW, int main_bytes) {
 #define ME_EPI_PRE 1
 #endif
 // epilogue_granule<EPI_STORE, MODE >= kEpiConst>: which options of the launch are compiled in
-constexpr int kEpiConst = 16, kEpiRes = 1, kEpiOut32 = 2, kEpiOut16 = 4, kEpiBorder = 8, kEpiLo = 32, kEpiHi2 = 64;
+constexpr int kEpiConst = 16, kEpiRes = 1, kEpiOut32 = 2, kEpiOut16 = 4, kEpiBorder = 8, kEpiLo = 32, kEpiHi2 = 64, kEpiResB = 128;
 struct EpiLane {
     float4 bias[2], gamma[2];  // per-lane constants for columns n..n+3 and n+4..n+7
     int q, co;                 // EPI_CONVT: n = q * Cout + co
@@ -405,7 +405,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
         // branch (a lower bound of 0 or -inf) -- see EPI_CONVT below for what the run-time checks cost a store-heavy launch.
         constexpr bool CF = MODE >= kEpiConst;
         const bool f_res = CF ? (MODE & kEpiRes) != 0 : p.res32 != nullptr;
-        const bool f_resb = CF ? false : p.res32b != nullptr;
+        const bool f_resb = CF ? (MODE & kEpiResB) != 0 : p.res32b != nullptr;
         const bool f_o32 = CF ? (MODE & kEpiOut32) != 0 : p.out32 != nullptr;
         const bool f_o16 = CF ? (MODE & kEpiOut16) != 0 : p.out16 != nullptr;
         const bool f_border = CF ? (MODE & kEpiBorder) != 0 : p.out16_border != 0;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
                 x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
             }
             if (f_resb) {
-                const float4 r4 = *reinterpret_cast<const float4*>(p.res32b + row32 + n + 4 * h);
+                const float4 r4 = (CF && ME_EPI_PRE) ? pre[2 + h] : *reinterpret_cast<const float4*>(p.res32b + row32 + n + 4 * h);
                 x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
             }
             float a0 = x0, a1 = x1, a2 = x2, a3 = x3;
@@ -807,10 +807,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 // it (the output may be the residual, for all the compiler knows) and a pass is ITERS memory latencies long.
                 // (A whole pass at once -- 8 registers per granule -- spills in the 256-register kernels.)
                 constexpr bool PRE = ME_EPI_PRE && EPI == EPI_STORE && MODE >= kEpiConst && (MODE & kEpiRes) != 0;
-                constexpr int PB = PRE ? (ITERS % 2 == 0 ? 2 : 1) : 1;
+                constexpr bool PRE_B = PRE && (MODE & kEpiResB) != 0;  // a second residual: one granule at a time (16 registers)
+                constexpr int PB = PRE && !PRE_B ? (ITERS % 2 == 0 ? 2 : 1) : 1;
 #pragma unroll
                 for (int it0 = 0; it0 < ITERS; it0 += PB) {
-                float4 pre[PB][2];
+                float4 pre[PB][4];
                 if constexpr (PRE) {
 #pragma unroll
                     for (int u = 0; u < PB; ++u) {
@@ -825,6 +826,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                         const float* src = p.res32 + (int64_t)(ok ? m_it : 0) * p.ldc + n;
                         pre[u][0] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
                         pre[u][1] = ok && hi_ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (PRE_B) {
+                            const float* srcb = p.res32b + (int64_t)(ok ? m_it : 0) * p.ldc + n;
+                            pre[u][2] = ok ? *reinterpret_cast<const float4*>(srcb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            pre[u][3] = ok && hi_ok ? *reinterpret_cast<const float4*>(srcb + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 }
                 if constexpr (LATE_V) {
@@ -881,12 +887,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             const bool simple = p.out16 && !p.out32 && !p.res32 && !p.res32b && !p.out16_border && p.bias &&
                                 !p.lo_off16 && !p.ldc16;
             // the convolutions' combinations (no second residual, no GELU): compiled-in options
-            const int mask = (p.res32 ? kEpiRes : 0) | (p.out32 ? kEpiOut32 : 0) | (p.out16 ? kEpiOut16 : 0) |
+            const int mask = (p.res32 ? kEpiRes : 0) | (p.res32b ? kEpiResB : 0) | (p.out32 ? kEpiOut32 : 0) | (p.out16 ? kEpiOut16 : 0) |
                              (p.out16_border ? kEpiBorder : 0) | (p.lo_off16 ? kEpiLo : 0) | (p.hi2_off16 ? kEpiHi2 : 0);
             // (not in the 352-row tile's kernel, MI == 11: it serves the ViT's qkv / fc1 through modes 1 and 2, and the other
             // bodies beside them cost it registers -- per-pass scratch reloads inside its store loops)
             constexpr bool CF_MODES = MI != 11;
-            const bool cf_ok = CF_MODES && !p.res32b && p.act != ACT_GELU && p.bias;
+            const bool cf_ok = CF_MODES && p.act != ACT_GELU && p.bias;
             if (simple && p.act == ACT_NONE)
                 run(std::integral_constant<int, 1>());
             else if (simple && p.act == ACT_GELU)
@@ -899,6 +905,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                         run(std::integral_constant<int, kEpiConst | kEpiOut32 | kEpiOut16 | kEpiBorder>());
                     else if (mask == (kEpiRes | kEpiOut32 | kEpiOut16 | kEpiBorder))
                         run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut32 | kEpiOut16 | kEpiBorder>());
+                    else if (mask == (kEpiRes | kEpiResB | kEpiOut32 | kEpiOut16 | kEpiBorder))
+                        run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiResB | kEpiOut32 | kEpiOut16 | kEpiBorder>());
                     else if (mask == (kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2))
                         run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2>());
                     else if (mask == (kEpiRes | kEpiOut16 | kEpiLo))
