@@ -530,7 +530,7 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
 // consecutive rows -- m0 is then the TILE index (image-major, tile rows, tile columns) and row t of the tile is pixel
 // (t >> 4, t & 15) of it; everything downstream sees the pixel's linear row index and coordinates as before.
 template <typename T, int EPI, int MI, int NI, int TM, int TN, int MI_CH, bool PIN_CONSTS = false,
-          typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false, int TILE_H = 16>
+          typename Hook = NoHook, int OUT8 = 0, bool TILE2D = false, int TILE_H = 16, bool CF_ALLOWED = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int m0, int n0,
                                               int wm, int wn, int lane, char* epi_lds,
                                               Hook after_loads = Hook(), int m_lim = -1) {
@@ -891,7 +891,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                              (p.out16_border ? kEpiBorder : 0) | (p.lo_off16 ? kEpiLo : 0) | (p.hi2_off16 ? kEpiHi2 : 0);
             // (not in the 352-row tile's kernel, MI == 11: it serves the ViT's qkv / fc1 through modes 1 and 2, and the other
             // bodies beside them cost it registers -- per-pass scratch reloads inside its store loops)
-            constexpr bool CF_MODES = MI != 11;
+            constexpr bool CF_MODES = CF_ALLOWED && MI != 11;  // (CF_ALLOWED false: the fp8 GEMM, whose 16-bit stores are mode 1)
             const bool cf_ok = CF_MODES && p.act != ACT_GELU && p.bias;
             if (simple && p.act == ACT_NONE)
                 run(std::integral_constant<int, 1>());

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp8_kernel(const GemmParams p) {
             char* scratch0 = smem + (ts ^ 1) * A_BYTES;
             const int wprev = ws == 0 ? 2 : ws - 1;
             char* scr = (group == 0 ? scratch0 : smem + W_RING + wprev * B_BYTES) + gw * SCR;
-            gemm_epilogue<f16, EPI, MI, NI, TM, TN, MI_CH, true, NoHook, OUT8>(p, acc, cur.m0, cur.n0, wm, wn, lane, scr);
+            gemm_epilogue<f16, EPI, MI, NI, TM, TN, MI_CH, true, NoHook, OUT8, false, 16, false>(p, acc, cur.m0, cur.n0, wm, wn, lane, scr);
         }
         if (!has_next) break;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
