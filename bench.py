@@ -35,6 +35,14 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/
 MFMA_PEAK_TFLOPS_FP8 = 5000.0  # dense MX-scaled fp8, MI355X_MICROARCH.md "Peak FP8 MFMA"
 HBM_PEAK_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
+# Box calibration.  ctx.calibrate() runs two FIXED loops of the library (csrc/calibrate.hip, never
+# to be edited): an MFMA-only loop and a 512 MiB device copy.  The reference below is the first box measured in round 5
+# (profiles/r05_calibration_boxes.json lists every box that produced a profiles/r05_* file); `value_normalised` is what
+# this run's rate would read on THAT box under a two-term model of the step -- CAL_MFMA_SHARE of its time scales with
+# the MFMA loop's rate (the matrix pipe at the clock the part holds), the rest with the copy's -- so that runs of
+# different rounds on different boxes can be put on one scale.  The raw calibration is printed beside it.
+CAL_REFERENCE = {"mfma_tflops": 0.0, "copy_gbs": 0.0}   # filled in from the first round-5 box
+CAL_MFMA_SHARE = 0.8
 
 
 def kernel_source_sha():
@@ -70,6 +78,62 @@ def pmc_traffic(kernel_name):
                 sum(v["mfma_util"] for v in ops) / n, f"profiles/r04_pmc_kernels.json, source sha {meta['source_sha']}")
     except Exception as e:   # no file: traffic stays null
         return None, None, None, f"no PMC file ({type(e).__name__})"
+
+
+# Node-level ceiling of the configs[4] chain (profiles/r04_node_write_ceiling.txt, tools/node_write_ceiling.py): 8 processes x 2
+# writer threads put 178 files/s of 110 MB onto one tmpfs -- the host kernel's page-cache copy, no GPU involved
+NODE_WRITE_CEILING_FILES_PER_S = 178.0
+
+
+def reduce_over_ranks(elapsed, my_step_ms, world, device):
+    """The contract's MAX over ranks of the timed region + every rank's own step time (torch.distributed must be
+    initialised; `device` is where the backend wants its tensors: "cuda" under RCCL, "cpu" under gloo)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank_ms = [None] * world
+    dist.all_gather_object(per_rank_ms, my_step_ms)
+    return float(t.item()), per_rank_ms
+
+
+def whole_job_rate(world, batch_per_gpu, steps, elapsed_max):
+    """`value`: the images ALL ranks processed in the timed region / the slowest rank's time"""
+    return world * batch_per_gpu * steps / elapsed_max
+
+
+def chain_ceiling_note(world, value):
+    """configs[4]: does this run ask the host for more OBJ files per second than one node's page cache takes?"""
+    over = value > NODE_WRITE_CEILING_FILES_PER_S
+    return {"files_per_s_this_run": round(value, 1), "node_ceiling_files_per_s": NODE_WRITE_CEILING_FILES_PER_S,
+            "source": "profiles/r04_node_write_ceiling.txt (8 processes x 2 pwrite threads, 110 MB files, one tmpfs, no GPU)",
+            "at_ceiling": bool(value > 0.85 * NODE_WRITE_CEILING_FILES_PER_S),
+            "note": (f"{world} rank(s) wrote {value:.0f} files/s; the host's page-cache copy takes about "
+                     f"{NODE_WRITE_CEILING_FILES_PER_S:.0f} files/s of this size per node" +
+                     (": the chain is bound by the host here, not by the GPUs -- a plateau from this rank count on is the "
+                      "file system's" if over or value > 0.85 * NODE_WRITE_CEILING_FILES_PER_S else
+                      f" ({NODE_WRITE_CEILING_FILES_PER_S / max(value / world, 1e-9):.1f} ranks at this per-GPU rate would reach it)"))}
+
+
+def calibration_object(cal, value):
+    """bench line's `calibration`: this box's two loop rates, the reference box's, and `value` restated for the
+    reference box (rank 0's device; at N > 1 every rank has its own box-to-box factor, rank 0's is quoted)."""
+    ref = CAL_REFERENCE
+    out = {"mfma_loop_tflops": round(cal["mfma_tflops"], 1), "mfma_loop_clock_ghz": round(cal["mfma_clock_ghz"], 4),
+           "copy_gbs": round(cal["copy_gbs"], 1), "mfma_loop_ms": round(cal["mfma_loop_ms"], 3),
+           "copy_ms": round(cal["copy_ms"], 4), "cus": cal["cus"],
+           "reference": dict(ref, box="the first box measured in round 5 (profiles/r05_calibration_boxes.json)"),
+           "model": f"step time = {CAL_MFMA_SHARE} x (MFMA-loop-bound) + {round(1 - CAL_MFMA_SHARE, 2)} x (copy-bound)",
+           "loops": "csrc/calibrate.hip (fixed: 256 x 512 threads x 40000 x 32 v_mfma_f32_16x16x32_f16, operands in "
+                    "registers; 10 x 512 MiB device copy), run after the timed region"}
+    if ref["mfma_tflops"] > 0 and ref["copy_gbs"] > 0 and cal["mfma_tflops"] > 0 and cal["copy_gbs"] > 0:
+        speed = CAL_MFMA_SHARE * cal["mfma_tflops"] / ref["mfma_tflops"] + (1 - CAL_MFMA_SHARE) * cal["copy_gbs"] / ref["copy_gbs"]
+        out["box_speed_vs_reference"] = round(speed, 4)
+        out["value_normalised"] = round(value / speed, 3)
+    else:
+        out["box_speed_vs_reference"] = None
+        out["value_normalised"] = None
+    return out
 
 
 def parse_args():
@@ -371,20 +435,17 @@ def main():
         for _ in range(n_e2e):
             ctx.extract_depth(rgb_host, f_norm)
         e2e_ms = (time.perf_counter() - t1) / n_e2e * 1e3
+    # calibration leg: outside the timed region, on a chip as warm as the steps left it (about 50 ms)
+    cal = ctx.calibrate()
     per_rank_ms = [my_step_ms]
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        per_rank_ms = [None] * world
-        dist.all_gather_object(per_rank_ms, my_step_ms)
+        elapsed, per_rank_ms = reduce_over_ranks(elapsed, my_step_ms, world, "cuda")
     assert bool(torch.isfinite(depth).all()), "non-finite depth"
     # device-result calls leave the flag alone (matrix_eyes_hip.h): this covers every warm-up and timed step
     assert ctx.status_flags() == 0, "an f16 operand overflowed during the benchmark (me_status_flags)"
 
     if rank == 0:
-        images = world * B * args.steps
-        value = images / elapsed
+        value = whole_job_rate(world, B, args.steps, elapsed)
         tflop_img = TFLOP_PER_IMAGE_NOFOV if args.no_fov else TFLOP_PER_IMAGE_FOV
         # dominant kernel: largest total time over the timed region
         dom = max(prof, key=lambda k: k["total_ms"])
@@ -457,6 +518,8 @@ def main():
                          "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1) if k["flops"] else None}
                         for k in kernels[:8]],
         }
+        out["calibration"] = calibration_object(cal, value)
+        out["value_normalised"] = out["calibration"]["value_normalised"]
         if args_chain:
             # configs[4]: `value` is whole-chain images/s; the legs are per image, host wall clock around synchronised
             # sections (depth = the model step, raster = DepthMap::new + stereogram kernels, obj = mesh index +
@@ -472,6 +535,7 @@ def main():
                                 "file_write_tmpfs": round(chain_report["obj_file"], 3)},
                             "obj_bytes": chain_report["obj_bytes"],
                             "write_behind": bool(write_behind),
+                            "node_write_ceiling": chain_ceiling_note(world, value),
                             "note": "the file write is the host kernel's page-cache copy (about 2.8 GB/s on tmpfs whatever the "
                                     "thread count); everything before it runs on the GPU.  With write_behind "
                                     "(me_ctx_set_write_behind) a host thread writes image i's file while the GPU works on "

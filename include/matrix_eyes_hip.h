@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ME_ABI_VERSION 3
+#define ME_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum {
@@ -53,7 +53,9 @@ enum {
 enum {
     ME_STATUS_OVERFLOW_16BIT = 1, /* a kernel rounded a magnitude beyond 65504 to an f16 operand (stored as +-inf) */
     ME_STATUS_SYNC_TIMEOUT = 2    /* a workgroup gave up waiting for its neighbours' LayerNorm statistics (the fused
-                                     residual epilogue; never seen on a healthy device): the result is not valid */
+                                     residual epilogue; needs its sibling workgroups co-resident: a second tenant on
+                                     the device's CUs or a CU mask can break that): the step's result is not valid.
+                                     The context then falls back to stand-alone LayerNorm launches (me_ln_fusion_state) */
 };
 
 /* ---- arithmetic type of the MFMA operands (accumulation is always f32) --------------- */
@@ -135,11 +137,19 @@ int32_t me_ctx_synchronize(me_ctx* ctx);
    The reference computes in f32 (decoder.rs:35-44: relu, conv, adds in f32); this back end rounds MFMA operands to
    16 bit.  An f16 operand holds magnitudes up to 65504: past it the operand is +-inf, and behind a conv + ReLU the
    branch drops out silently.  Every kernel that writes 16-bit operands therefore raises ME_STATUS_OVERFLOW_16BIT
-   when that happens.  me_extract_depth[_u8] with a result in HOST memory clears the flag when it starts and fails
-   with ME_ERR_OVERFLOW itself; with a DEVICE result the call is asynchronous and never touches the flag: it stays
-   raised over any number of calls (and graph replays) until the caller asks here.  bf16 operands (ME_DTYPE_BF16)
-   have f32's range and never raise it. */
+   when that happens.  The word is sticky: no call clears it when it starts.  me_extract_depth[_u8] with a result in
+   HOST memory checks it when it has finished, fails with ME_ERR_OVERFLOW itself (also for an overflow that an earlier
+   asynchronous call left unread) and clears the bit it reports; with a DEVICE result the call is asynchronous and
+   never touches the flag: it stays raised over any number of calls (and graph replays) until the caller asks here.
+   bf16 operands (ME_DTYPE_BF16) have f32's range and never raise it.
+   ME_STATUS_SYNC_TIMEOUT: a host-result call that meets it runs its step once more on stand-alone LayerNorm launches
+   (bit for bit the ME_LN_FUSE=0 result) and succeeds; after device-result calls the NEXT me_extract_depth[_u8] on the
+   context fails with ME_ERR_HIP (the earlier depth maps are invalid) and the one after that runs unfused. */
 int32_t me_status_flags(me_ctx* ctx, uint32_t* flags);
+/* Whether the residual launches of the ViT still carry the LayerNorm behind them (1) or the context has fallen back
+   to stand-alone LayerNorm launches (0: after an ME_STATUS_SYNC_TIMEOUT, see above; me_last_error holds the note
+   logged then), and how many steps were run again because of it.  Either pointer may be NULL. */
+int32_t me_ln_fusion_state(me_ctx* ctx, int32_t* fused, int32_t* fallbacks);
 
 /* ---- weights: mod.rs:174-249 load_record ---------------------------------------------
    Tensors are handed over under their PyTorch checkpoint names and layouts (SURVEY App. C:

@@ -116,6 +116,11 @@ int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8
    printed as Rust's `{}` prints an f64 -- shortest round-trip digits, positional notation -- into the `stride`-byte
    slot i of `text` (stride >= 344), its length into lengths[i]. */
 int32_t me_op_format_f64(me_ctx* ctx, const double* values, int64_t count, char* text, int32_t stride, int32_t* lengths);
+/* Box calibration (csrc/calibrate.hip; bench.py's `calibration` object): two FIXED loops on the context's stream, about
+   50 ms, synchronous.  out[0] = TFLOP/s of an MFMA-only loop (v_mfma_f32_16x16x32_f16, operands in registers, two waves per
+   SIMD on 256 workgroups), out[1] = the shader clock the part held inside it (GHz, s_memtime / s_memrealtime),
+   out[2] = GB/s (read + written) of a 512 MiB device copy, out[3] = the loop's ms, out[4] = ms per copy, out[5] = CUs. */
+int32_t me_calibrate(me_ctx* ctx, double* out6);
 /* f32 <-> context 16-bit type */
 int32_t me_op_cast_to16(me_ctx* ctx, const float* src, void* dst16, int64_t count);
 int32_t me_op_cast_to32(me_ctx* ctx, const void* src16, float* dst, int64_t count);

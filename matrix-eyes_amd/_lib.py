@@ -47,6 +47,7 @@ SIGNATURES = {
     "me_ctx_set_stream": (_i32, [_vp, _vp]),
     "me_ctx_synchronize": (_i32, [_vp]),
     "me_status_flags": (_i32, [_vp, C.POINTER(_u32)]),
+    "me_ln_fusion_state": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "me_load_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     "me_expected_weight_count": (_i32, [_vp]),
     "me_expected_weight": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i32)]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "me_op_linear_residual_layernorm_fp8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                                    C.POINTER(_vp), C.POINTER(_vp), _f32, _vp, _vp, _vp]),
     "me_op_format_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
+    "me_calibrate": (_i32, [_vp, C.POINTER(C.c_double)]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),
     "me_op_cast_to32": (_i32, [_vp, _vp, _vp, _i64]),
     "me_profile_enable": (_i32, [_vp, _i32]),

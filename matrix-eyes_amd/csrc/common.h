@@ -250,6 +250,15 @@ struct GemmParams {
     float ln_eps;
     unsigned long long* ln_stats;
     unsigned* ln_count;
+    // polls a workgroup spends waiting for its row tile's other column tiles before it raises ME_STATUS_SYNC_TIMEOUT
+    // (0: 2^20, about 2 s; gemm_launch fills it in from ME_LN_SPIN_LIMIT, a test knob)
+    int32_t ln_spin_limit;
+    // compute units the launch stream may use when that is fewer than the device has (a stream created with a CU mask;
+    // gemm_launch fills it in, gemm.hip stream_cu_count): persistent grids are sized from it.  0: all of them
+    int32_t cu_granted;
+    // query form (gemm.hip gemm_lnf_resident): the launcher writes the number of workgroups it would keep resident
+    // here and returns without launching.  Host pointer; null for a launch
+    int32_t* resident_out;
     // development A/B (ME_GELU_BATCH=0): fc1's GELU four values at a time instead of a pass's sixteen at once
     int32_t gelu_per_granule;
     // persistent kernels: at most this many workgroups (a multiple of 8), so that a launch on another stream finds
@@ -277,6 +286,13 @@ void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, h
 // The depth head's final 3x3 (128 -> 32) + 1x1 (32 -> 1) on a pixel halo tile with the weights held in registers
 // (head_conv.hip); gemm_launch takes it for EPI_HEAD_FINAL where the shape fits (ME_HEAD_HALO=0: the implicit-GEMM tile)
 bool head_final_halo_fits(const GemmParams& p);
+// compute units `stream` may use: the bits of its CU mask (hipExtStreamGetCUMask), the device's count when the stream
+// has no mask or the runtime cannot say
+int stream_cu_count(hipStream_t stream);
+// workgroups of the fused residual + LayerNorm launch (gemm_core.h resid_ln_epilogue) that are resident at once on
+// the CUs `stream` may use; a launch with N columns needs 8 * N / 256 of them (one row tile per XCD with all its column
+// tiles: they wait for one another)
+int gemm_lnf_resident(int32_t dtype, hipStream_t stream);
 void head_final_halo_launch(const GemmParams& p, int32_t dtype, hipStream_t stream);
 
 // MX fp8 x fp8 (gemm_fp8.hip): EPI_STORE (f16 out16, or fp8 out8 + scales) / EPI_RESID_SCALE

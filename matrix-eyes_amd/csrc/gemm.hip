@@ -154,9 +154,58 @@ static unsigned* queue_for_stream(hipStream_t stream) {
     return q;
 }
 
+// Compute units a stream may use.  A stream created with hipExtStreamCreateWithCUMask (or a process under a global CU
+// mask) gets fewer than the device reports; a persistent grid sized from the device's count would then queue workgroups
+// behind one another -- harmless for the plain kernels, a wait without partner for the fused LayerNorm launch.
+int stream_cu_count(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int> cache;
+    int dev = 0;
+    ME_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, stream});
+    if (it != cache.end()) return it->second;
+    int cus = 0;
+    ME_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int granted = cus;
+    uint32_t mask[32] = {0};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing && hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
+        int bits = 0;
+        for (uint32_t w : mask) bits += __builtin_popcount(w);
+        if (bits > 0 && bits < cus) granted = bits;
+    }
+    (void)hipGetLastError();
+    if (!capturing) cache[{dev, stream}] = granted;
+    return granted;
+}
+
+int gemm_lnf_resident(int32_t dtype, hipStream_t stream) {
+    GemmParams p = GemmParams();
+    int32_t resident = 0;
+    p.resident_out = &resident;
+    p.cu_granted = stream_cu_count(stream);
+    p.ln_out16 = &resident;  // (selects the LNF instantiation; nothing is launched)
+    p.K = 128;
+    if (dtype == ME_DTYPE_F16)
+        gemm_dispatch<f16, A_PLAIN, EPI_RESID_SCALE>(p, CFG_PP352, stream);
+    else if (dtype == ME_DTYPE_BF16)
+        gemm_dispatch<bf16, A_PLAIN, EPI_RESID_SCALE>(p, CFG_PP352, stream);
+    else
+        fail(ME_ERR_BAD_ARG, "gemm: bad dtype %d", dtype);
+    return resident;
+}
+
 void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype, hipStream_t stream,
                  int32_t force_cfg) {
     GemmParams p = p_in;
+    p.resident_out = nullptr;
+    p.cu_granted = stream_cu_count(stream);
+    {
+        static const int spin = getenv("ME_LN_SPIN_LIMIT") ? atoi(getenv("ME_LN_SPIN_LIMIT")) : 0;  // test knob
+        p.ln_spin_limit = spin > 0 ? spin : 0;
+    }
     // Dynamic tile order (TileQueue in gemm_core.h) is an opt-in: measured on the full step it gains 0.4 %
     // (26.57 vs 26.68 ms) -- the launches the side streams disturb most (proj / fc2) have two tiles per
     // workgroup, too coarse for a late workgroup to hand work to its neighbours.

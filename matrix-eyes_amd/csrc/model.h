@@ -120,7 +120,7 @@ struct me_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // The side branch of extract_depth (api.hip extract_depth_impl): the latency-bound low-resolution decoder levels and
     // the FOV tail run on `side_stream` beside the bandwidth-bound ConvTranspose chains of the encoder's two latents,
-    // forked and joined by events (captured into the step's hipGraph like any other dependency).  ME_OVERLAP_TAIL=0, a
+    // forked and joined by events (captured into the step's hipGraph like any other dependency).  Opt-in (ME_OVERLAP_TAIL=1); a
     // progress callback or per-kernel timing keep the step on one stream.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -150,6 +150,17 @@ struct me_ctx {
     // me_status_flags: one device word the kernels OR bits into (ME_STATUS_OVERFLOW_16BIT: an f16 operand store
     // met a magnitude beyond 65504, common.h raise_overflow16)
     unsigned* status_dev = nullptr;
+    // Pinned host mirror of the status word: every step whose result stays on the device ends with an asynchronous copy
+    // of the word into it, so the NEXT entry into the library sees what earlier asynchronous steps raised without
+    // synchronising anything (api.hip check_pending_status).
+    volatile unsigned* status_host = nullptr;
+    // The fused residual + LayerNorm launch waits on sibling workgroups inside the launch (gemm_core.h
+    // resid_ln_epilogue), which needs them co-resident.  When a step reports ME_STATUS_SYNC_TIMEOUT (a second tenant on
+    // the device, a CU mask the runtime does not report) the context latches this, the step is run again with the
+    // stand-alone LayerNorm launches (bit for bit the ME_LN_FUSE=0 result), and fusion stays off for the context.
+    bool ln_fuse_off = false;
+    int32_t ln_fallbacks = 0;     // steps re-run because of it (me_ln_fusion_state)
+    std::string ln_fuse_note;     // logged once: why fusion went off
 
     // Write-behind of OBJ files (me_ctx_set_write_behind): the text of mesh call i is written to its file by a host
     // thread while the caller goes on to image i + 1.  One slot = a pinned host staging buffer (the OBJ text's D2H
@@ -280,5 +291,8 @@ void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev);
 void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
 
 void report(me_ctx* ctx, float pos, const char* msg);
+
+// calibrate.hip: the two fixed loops of bench.py's calibration leg (out[6])
+void calibrate(me_ctx* ctx, double* out);
 
 }  // namespace me

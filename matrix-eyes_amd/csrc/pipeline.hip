@@ -445,7 +445,12 @@ struct MergedVit {
         static const bool tall = !(getenv("ME_GEMM_TALL") && atoi(getenv("ME_GEMM_TALL")) == 0);
         static const bool pp192 = getenv("ME_GEMM_PP192") != nullptr;
         const int C = ctx->C();
-        return enabled && tall && !pp192 && (C == 256 || C == 512 || C == 1024);
+        if (!(enabled && tall && !pp192 && (C == 256 || C == 512 || C == 1024))) return false;
+        // the context has seen the exchange time out (api.hip run_with_ln_fallback): stand-alone LayerNorm from then on
+        if (ctx->ln_fuse_off) return false;
+        // one row tile per XCD with all its column tiles must be resident at once on the CUs the stream may use
+        // (a smaller part, a partition mode, a stream with a CU mask): otherwise the stand-alone LayerNorm
+        return gemm_lnf_resident(ctx->dtype, s) >= 8 * (C / 256);
     }
     // returns true when xn holds LayerNorm(ln) of the updated rows
     bool resid_all(const char* A, int K, const void* w0, const float* bb0, const float* g0, const void* w1,

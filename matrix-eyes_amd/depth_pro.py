@@ -89,6 +89,22 @@ class Context:
         self._check(self.lib.me_status_flags(self._h, C.byref(flags)))
         return int(flags.value)
 
+    def calibrate(self):
+        """The two fixed calibration loops (csrc/calibrate.hip): what THIS device gives on an MFMA-only loop and on a
+        device copy -- bench.py prints it beside the step time so that runs on different boxes can be compared."""
+        out = (C.c_double * 6)()
+        self._check(self.lib.me_calibrate(self._h, out))
+        return {"mfma_tflops": out[0], "mfma_clock_ghz": out[1], "copy_gbs": out[2], "mfma_loop_ms": out[3],
+                "copy_ms": out[4], "cus": int(out[5])}
+
+    def ln_fusion_state(self):
+        """(fused, fallbacks): whether the ViT's residual launches still carry the LayerNorm behind them, and how many
+        steps were run again on stand-alone LayerNorm launches after an ME_STATUS_SYNC_TIMEOUT
+        (matrix_eyes_hip.h me_ln_fusion_state)."""
+        fused, fallbacks = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.me_ln_fusion_state(self._h, C.byref(fused), C.byref(fallbacks)))
+        return bool(fused.value), int(fallbacks.value)
+
     def last_mesh_timing(self):
         """legs of the last output_mesh(".obj") call in ms: {mesh, format, d2h, file} and the text size"""
         ms = (C.c_double * 4)()

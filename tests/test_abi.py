@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_default_config(lib):
-    assert lib.me_abi_version() == 3
+    assert lib.me_abi_version() == 4
     c = L.CModelConfig()
     assert lib.me_default_config(C.byref(c)) == 0
     d = m.ModelConfig().to_c()

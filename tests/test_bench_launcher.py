@@ -85,3 +85,44 @@ def test_interrupting_the_launcher_ends_the_ranks(tmp_path):
     assert p.wait(timeout=20) == 130
     time.sleep(0.2)
     assert not any(_alive(q) for q in pids)
+
+
+RANK_STUB = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+steps, B = 20, 8
+my_step_ms = 170.0 + 1.5 * rank                  # every rank its own pace; rank 7 is the slowest
+elapsed, per_rank = bench.reduce_over_ranks(my_step_ms * steps / 1e3, my_step_ms, world, "cpu")
+if rank == 0:
+    value = bench.whole_job_rate(world, B, steps, elapsed)
+    print(json.dumps({"n_gpus": world, "value": value, "per_rank_ms_per_step": per_rank, "elapsed": elapsed,
+                      "chain": bench.chain_ceiling_note(world, value)}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_eight_ranks_aggregate_like_the_contract_says(tmp_path):
+    """what `python bench.py --gpus 8` reduces over its ranks, rehearsed on the CPU (gloo) through
+    bench.py's own launcher and its own reduction code: eight per-rank step times, `value` = the images of ALL ranks
+    / the SLOWEST rank's time, and the configs[4] note that says when the node's file system is the bound."""
+    import json
+    stub = tmp_path / "rank.py"
+    stub.write_text(RANK_STUB)
+    out = tmp_path / "out.json"
+    code = (f"import sys, types; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"sys.exit(bench.launch_ranks(types.SimpleNamespace(gpus=8), child_cmd=[sys.executable, {str(stub)!r}, {ROOT!r}], timeout_s=300))")
+    r = subprocess.run([sys.executable, "-c", code], stdout=open(out, "w"), stderr=subprocess.PIPE, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(out.read_text().strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and len(line["per_rank_ms_per_step"]) == 8
+    assert line["per_rank_ms_per_step"] == [170.0 + 1.5 * r for r in range(8)]
+    slowest_s = (170.0 + 1.5 * 7) * 20 / 1e3
+    assert abs(line["elapsed"] - slowest_s) < 1e-9 and abs(line["value"] - 8 * 8 * 20 / slowest_s) < 1e-6
+    # 8 ranks x 8 images / 0.1805 s = 355 files/s: past the node's 178 -> the line explains its own plateau
+    assert line["chain"]["at_ceiling"] and "bound by the host" in line["chain"]["note"]
+    assert not bench.chain_ceiling_note(1, 36.7)["at_ceiling"] and "ranks at this per-GPU rate" in bench.chain_ceiling_note(1, 36.7)["note"]

@@ -71,9 +71,10 @@ def run_pass(op, cfg, counters, work):
     out = os.path.join(work, f"{op}_{'_'.join(counters)}"[:80])
     probe, rows = (SHAPES[op][0], SHAPES[op][3]) if op in SHAPES else (op, PROBE_M)
     # the interpreter itself after `--`, never a launcher script: the profiler's preloaded library has initialised
-    # the GPU by then and this pool forbids an exec hop from such a process
+    # the GPU by then and this pool forbids an exec hop from such a process.  sys.executable as it is: a symlink is not
+    # an exec hop, and resolving it would lose a venv's pyvenv.cfg and with it torch / numpy
     cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
-           "--", os.path.realpath(sys.executable), os.path.join(ROOT, "tools", "gemm_probe.py"), probe, str(cfg), "6"]
+           "--", sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), probe, str(cfg), "6"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PROBE_M=str(rows)),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, text=True)
     if r.returncode != 0:
