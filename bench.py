@@ -41,7 +41,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
 # this run's rate would read on THAT box under a two-term model of the step -- CAL_MFMA_SHARE of its time scales with
 # the MFMA loop's rate (the matrix pipe at the clock the part holds), the rest with the copy's -- so that runs of
 # different rounds on different boxes can be put on one scale.  The raw calibration is printed beside it.
-CAL_REFERENCE = {"mfma_tflops": 0.0, "copy_gbs": 0.0}   # filled in from the first round-5 box
+CAL_REFERENCE = {"mfma_tflops": 1954.0, "copy_gbs": 4882.0}   # gpurun_out/r05a: the two bench runs of the first round-5 box
 CAL_MFMA_SHARE = 0.8
 
 
@@ -113,6 +113,23 @@ def chain_ceiling_note(world, value):
                      (": the chain is bound by the host here, not by the GPUs -- a plateau from this rank count on is the "
                       "file system's" if over or value > 0.85 * NODE_WRITE_CEILING_FILES_PER_S else
                       f" ({NODE_WRITE_CEILING_FILES_PER_S / max(value / world, 1e-9):.1f} ranks at this per-GPU rate would reach it)"))}
+
+
+def kernel_row(k, steps):
+    """One row of the bench line's kernels[]: time, rate on the algorithmic FLOPs, rate on the algorithmic BYTES (every
+    operand of the launch once, gemm.hip), both as fractions of the quoted peaks, and which of the two bounds the launch
+    sits closer to -- the MFMA fraction alone misstates the memory-bound launches (proj's residual read-modify-write, the
+    ConvTransposes' pixel-shuffle stores, the f32-residual convolutions)."""
+    sec = k["total_ms"] * 1e-3
+    tf = k["flops"] / sec / 1e12 if k["flops"] else None
+    gbs = k["bytes"] / sec / 1e9 if k.get("bytes") else None
+    peak = MFMA_PEAK_TFLOPS_FP8 if "<fp8," in k["kernel"] else MFMA_PEAK_TFLOPS
+    mf = tf / peak if tf else None
+    hf = gbs / HBM_PEAK_GBS if gbs else None
+    return {"kernel": k["kernel"], "launches_per_step": k["launches"] / steps, "ms_per_step": round(k["total_ms"] / steps, 4),
+            "tflops": None if tf is None else round(tf, 1), "mfma_frac": None if mf is None else round(mf, 3),
+            "algorithmic_gbs": None if gbs is None else round(gbs, 0), "hbm_frac": None if hf is None else round(hf, 3),
+            "bound": None if (mf is None and hf is None) else ("hbm" if (hf or 0) > (mf or 0) else "mfma")}
 
 
 def calibration_object(cal, value):
@@ -345,6 +362,7 @@ def main():
     f_norm = torch.ones(B, device="cuda") if args.no_fov else None   # on the device: no host pointer in the call
 
     chain_ms = {"depth": 0.0, "raster": 0.0, "obj": 0.0, "obj_bytes": 0, "obj_device": 0.0, "obj_d2h": 0.0, "obj_file": 0.0}
+    chain_pipelined = False
     if args.chain:
         # BASELINE configs[4] per image: depth -> DepthMap::new (clamp + range, output.rs:44-75) -> stereogram
         # (output.rs:141-193) -> textured OBJ + MTL (output.rs:195-261) written to a file on tmpfs
@@ -357,40 +375,80 @@ def main():
         # file is complete (me_output_flush) before the timed region ends.  ME_CHAIN_SYNC_WRITES=1: the reference's form.
         write_behind = os.environ.get("ME_CHAIN_SYNC_WRITES") is None
         ctx.set_write_behind(max(2, B) if write_behind else 0)
+        # me_ctx_set_output_overlap: step k + 1's depth is queued BEFORE step k's output calls, which run
+        # on the context's output stream behind the step that wrote their buffer -- the GPU works on the next depth maps
+        # while the host waits for this step's mesh counts, OBJ text and its D2H copy.  Two depth buffers in turn.
+        # ME_CHAIN_SERIAL=1: round 4's form (depth, synchronise, raster, synchronise, OBJ).
+        chain_pipelined = os.environ.get("ME_CHAIN_SERIAL") is None
+        ctx.set_output_overlap(chain_pipelined)
+        depth_bufs = [depth, torch.empty_like(depth)]
     chain_step = [0]
 
-    def step():
-        if not args.chain:
-            ctx.extract_depth(rgb, f_norm, out=depth)
-            return
-        t0 = time.perf_counter()
-        ctx.extract_depth(rgb, f_norm, out=depth)
-        ctx.synchronize()
+    def chain_outputs(k, timed_legs):
+        """DepthMap::new -> stereogram -> textured OBJ for the B images of step k (depth buffer k & 1)"""
+        buf = depth_bufs[k & 1]
         t1 = time.perf_counter()
-        maps = [m.DeviceDepthMap(ctx, depth[b], (S, S)) for b in range(B)]
+        maps = [m.DeviceDepthMap(ctx, buf[b], (S, S)) for b in range(B)]
         for b in range(B):
             maps[b].stereogram(1.0 / 16.0, noise, out=stereo[b])
-        ctx.synchronize()
+        if timed_legs:
+            ctx.synchronize()
         t2 = time.perf_counter()
         chain_step[0] += 1
         for b in range(B):
             # two names per image slot: a file still being written behind the caller is never the next call's target
             path = os.path.join(out_dir, f"mesh{b}_{chain_step[0] & 1}.obj")
             maps[b].output_mesh(path, "photo.jpg", m.VertexMode.Texture)
-            legs = ctx.last_mesh_timing()
-            chain_ms["obj_bytes"] = legs["bytes"]
-            chain_ms["obj_device"] += legs["mesh_ms"] + legs["format_ms"]
-            chain_ms["obj_d2h"] += legs["d2h_ms"]
-            chain_ms["obj_file"] += legs["file_ms"]
+            if timed_legs:
+                legs = ctx.last_mesh_timing()
+                chain_ms["obj_bytes"] = legs["bytes"]
+                chain_ms["obj_device"] += legs["mesh_ms"] + legs["format_ms"]
+                chain_ms["obj_d2h"] += legs["d2h_ms"]
+                chain_ms["obj_file"] += legs["file_ms"]
         t3 = time.perf_counter()
-        chain_ms["depth"] += (t1 - t0) * 1e3
-        chain_ms["raster"] += (t2 - t1) * 1e3
-        chain_ms["obj"] += (t3 - t2) * 1e3
+        if timed_legs:
+            chain_ms["raster"] += (t2 - t1) * 1e3
+            chain_ms["obj"] += (t3 - t2) * 1e3
 
-    for _ in range(args.warmup):
-        step()
-    for k in ("depth", "raster", "obj", "obj_device", "obj_d2h", "obj_file"):
-        chain_ms[k] = 0.0
+    def step():
+        ctx.extract_depth(rgb, f_norm, out=depth)
+
+    def chain_serial(n, timed_legs):
+        """every leg behind the one before it, synchronised: the per-leg diagnostic (and ME_CHAIN_SERIAL=1's timed form)"""
+        for k in range(n):
+            t0 = time.perf_counter()
+            ctx.extract_depth(rgb, f_norm, out=depth_bufs[k & 1])
+            ctx.synchronize()
+            if timed_legs:
+                chain_ms["depth"] += (time.perf_counter() - t0) * 1e3
+            chain_outputs(k, timed_legs)
+
+    chain_host = {"enqueue_depth": 0.0, "output_calls": 0.0, "steps": 0}
+
+    def chain_pipeline(n):
+        """step k + 1's depth queued before step k's output calls; nothing synchronised between legs"""
+        ctx.extract_depth(rgb, f_norm, out=depth_bufs[0])
+        for k in range(n):
+            h0 = time.perf_counter()
+            if k + 1 < n:
+                ctx.extract_depth(rgb, f_norm, out=depth_bufs[(k + 1) & 1])
+            h1 = time.perf_counter()
+            chain_outputs(k, False)
+            chain_host["enqueue_depth"] += (h1 - h0) * 1e3
+            chain_host["output_calls"] += (time.perf_counter() - h1) * 1e3
+            chain_host["steps"] += 1
+
+    def run_steps(n):
+        if not args.chain:
+            for _ in range(n):
+                step()
+        elif chain_pipelined:
+            chain_pipeline(n)
+        else:
+            chain_serial(n, False)
+
+    run_steps(args.warmup)
+    chain_host.update(enqueue_depth=0.0, output_calls=0.0, steps=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -402,18 +460,23 @@ def main():
         ctx.output_flush()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     if args.chain:
         ctx.output_flush()          # every OBJ file of the timed steps is on the file system
     fence()
     elapsed = time.perf_counter() - t0
     my_step_ms = elapsed / args.steps * 1e3
-    chain_report = {k: (v / (args.steps * B) if k != "obj_bytes" else v) for k, v in chain_ms.items()}
     if args.chain:
+        # per-leg diagnostic: a separate pass, synchronised between legs (never the timed region of the pipelined form)
+        n_diag = max(2, min(5, args.steps))
+        chain_serial(n_diag, True)
+        ctx.output_flush()
+        chain_report = {k: (v / (n_diag * B) if k != "obj_bytes" else v) for k, v in chain_ms.items()}
         shutil.rmtree(out_dir, ignore_errors=True)
+        ctx.set_output_overlap(False)
         args_chain, args.chain = True, False      # the roofline / end-to-end legs below time the depth step itself
     else:
+        chain_report = {}
         args_chain = False
     graph_replays = ctx.graph_launch_count
     # roofline leg: the same steps once more with every GEMM / attention / LayerNorm launch bracketed
@@ -513,10 +576,7 @@ def main():
                 "share_of_profiled_kernel_time": round(dom["total_ms"] / prof_ms, 3),
                 "whole_step_frac": round(value / world * tflop_img / MFMA_PEAK_TFLOPS, 4),
             },
-            "kernels": [{"kernel": k["kernel"], "launches_per_step": k["launches"] / args.steps,
-                         "ms_per_step": round(k["total_ms"] / args.steps, 4),
-                         "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 1) if k["flops"] else None}
-                        for k in kernels[:8]],
+            "kernels": [kernel_row(k, args.steps) for k in kernels[:10]],
         }
         out["calibration"] = calibration_object(cal, value)
         out["value_normalised"] = out["calibration"]["value_normalised"]
@@ -535,6 +595,14 @@ def main():
                                 "file_write_tmpfs": round(chain_report["obj_file"], 3)},
                             "obj_bytes": chain_report["obj_bytes"],
                             "write_behind": bool(write_behind),
+                            "pipelined": bool(chain_pipelined),
+                            "host_ms_per_step": ({k: round(v / max(1, chain_host["steps"]), 3) for k, v in chain_host.items() if k != "steps"}
+                                                 if chain_pipelined else None),
+                            "form": ("step k + 1's me_extract_depth is queued before step k's output calls, which run on the "
+                                     "context's output stream behind the step that wrote their depth buffer "
+                                     "(me_ctx_set_output_overlap); nothing is synchronised between legs inside the timed region; "
+                                     "the *_ms_per_image legs are a separate, synchronised diagnostic pass"
+                                     if chain_pipelined else "serial: every leg synchronised (ME_CHAIN_SERIAL=1)"),
                             "node_write_ceiling": chain_ceiling_note(world, value),
                             "note": "the file write is the host kernel's page-cache copy (about 2.8 GB/s on tmpfs whatever the "
                                     "thread count); everything before it runs on the GPU.  With write_behind "

@@ -316,6 +316,15 @@ int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width, int32_t h
    me_ctx_set_write_behind, or me_output_flush, which waits for every pending file.  me_ctx_destroy flushes.  0 (the default): the reference's
    form, output_mesh returns with the file written. */
 int32_t me_ctx_set_write_behind(me_ctx* ctx, int32_t files_in_flight);
+/* Output overlap (BASELINE configs[4]; reconstruction.rs:155-205 runs extract_depth -> DepthMap::new -> output_image per
+   image, one after the other): with on = 1 every output back-end call of this section that reads a DEVICE depth buffer
+   runs on a second stream of the context, ordered behind the me_extract_depth[_u8] call that WROTE that buffer (known by
+   its address) instead of behind everything queued since.  A caller that alternates two device depth buffers can
+   therefore queue image i + 1's me_extract_depth first and then make image i's output calls: the GPU works on the next
+   depth map while the host waits for this image's mesh counts, OBJ text and its copy to the host.  The next
+   me_extract_depth that writes a buffer waits (on the GPU) for the output calls still reading it.  me_ctx_synchronize
+   and me_output_flush wait for both streams.  Results are unchanged.  0 (the default): one stream, the reference's order. */
+int32_t me_ctx_set_output_overlap(me_ctx* ctx, int32_t on);
 int32_t me_output_flush(me_ctx* ctx);
 
 /* The OBJ text of me_output_mesh without the file: the mesh is indexed and every "vt" / "v" / "f" line formatted on

@@ -78,6 +78,7 @@ extern "C" {
     pub fn me_ctx_synchronize(ctx: *mut MeCtx) -> i32;
     pub fn me_status_flags(ctx: *mut MeCtx, flags: *mut u32) -> i32;
     pub fn me_ln_fusion_state(ctx: *mut MeCtx, fused: *mut i32, fallbacks: *mut i32) -> i32;
+    pub fn me_ctx_set_output_overlap(ctx: *mut MeCtx, on: i32) -> i32;
     pub fn me_load_weight(ctx: *mut MeCtx, name: *const c_char, data: *const c_void, weight_dtype: i32, dims: *const i64, ndim: i32) -> i32;
     pub fn me_expected_weight_count(ctx: *const MeCtx) -> i32;
     pub fn me_expected_weight(ctx: *const MeCtx, index: i32, name: *mut *const c_char, dims: *mut i64, ndim: *mut i32) -> i32;

@@ -48,6 +48,7 @@ SIGNATURES = {
     "me_ctx_synchronize": (_i32, [_vp]),
     "me_status_flags": (_i32, [_vp, C.POINTER(_u32)]),
     "me_ln_fusion_state": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "me_ctx_set_output_overlap": (_i32, [_vp, _i32]),
     "me_load_weight": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     "me_expected_weight_count": (_i32, [_vp]),
     "me_expected_weight": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i32)]),

@@ -113,6 +113,85 @@ void check_pending_status(me_ctx* ctx) {
 }
 }  // namespace
 
+namespace me {
+namespace {
+me_ctx::DepthSlot* find_depth_slot(me_ctx* ctx, const void* p) {
+    const char* q = (const char*)p;
+    for (me_ctx::DepthSlot& s : ctx->depth_slots)
+        if (s.base && q >= s.base && q < s.base + s.bytes) return &s;
+    return nullptr;
+}
+}  // namespace
+
+OutputScope::OutputScope(me_ctx* c, const void* depth) : ctx(c) {
+    if (!c->output_overlap || !c->out_stream || c->capturing) return;
+    saved = c->stream;
+    me_ctx::DepthSlot* s = depth && is_device_ptr(depth) ? find_depth_slot(c, depth) : nullptr;
+    if (s && s->has_produced) {
+        ME_HIP(hipStreamWaitEvent(c->out_stream, s->produced, 0));
+        slot = (int)(s - c->depth_slots);
+    } else {
+        // a buffer no step of this context has written (a caller's own depth, a host pointer): behind everything queued so far
+        hipEvent_t ev = nullptr;
+        ME_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        const hipError_t e1 = hipEventRecord(ev, saved), e2 = e1 == hipSuccess ? hipStreamWaitEvent(c->out_stream, ev, 0) : e1;
+        (void)hipEventDestroy(ev);  // (released once it has completed)
+        ME_HIP(e2);
+    }
+    c->stream = c->out_stream;
+    active = true;
+}
+OutputScope::~OutputScope() {
+    if (!active) return;
+    if (slot >= 0) {
+        me_ctx::DepthSlot& s = ctx->depth_slots[slot];
+        if (!s.consumed && hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) s.consumed = nullptr;
+        if (s.consumed && hipEventRecord(s.consumed, ctx->out_stream) == hipSuccess) s.has_consumed = true;
+    }
+    ctx->stream = saved;
+}
+}  // namespace me
+
+namespace {
+// the step that is about to write [out, out + bytes): behind every output call that still reads an overlapping buffer
+void wait_for_consumers(me_ctx* ctx, const void* out, size_t bytes) {
+    if (!ctx->output_overlap) return;
+    const char* lo = (const char*)out;
+    for (me_ctx::DepthSlot& s : ctx->depth_slots)
+        if (s.base && s.has_consumed && lo < s.base + s.bytes && s.base < lo + bytes) {
+            ME_HIP(hipStreamWaitEvent(ctx->stream, s.consumed, 0));
+            s.has_consumed = false;
+        }
+}
+// ... and, once it is queued, known as the producer of that range
+void mark_produced(me_ctx* ctx, const void* out, size_t bytes) {
+    if (!ctx->output_overlap) return;
+    me_ctx::DepthSlot* slot = nullptr;
+    for (me_ctx::DepthSlot& s : ctx->depth_slots)
+        if (s.base == (const char*)out) slot = &s;
+    if (!slot)
+        for (me_ctx::DepthSlot& s : ctx->depth_slots)
+            if (!s.base) {
+                slot = &s;
+                break;
+            }
+    if (!slot) {
+        slot = &ctx->depth_slots[0];
+        for (me_ctx::DepthSlot& s : ctx->depth_slots)   // the least recently produced
+            if (s.stamp < slot->stamp) slot = &s;
+    }
+    if (slot->base != (const char*)out && slot->has_consumed) {
+        // the range this slot stood for is forgotten: nothing may still be reading it unordered
+        ME_HIP(hipStreamWaitEvent(ctx->stream, slot->consumed, 0));
+        slot->has_consumed = false;
+    }
+    if (!slot->produced) ME_HIP(hipEventCreateWithFlags(&slot->produced, hipEventDisableTiming));
+    slot->base = (const char*)out, slot->bytes = bytes, slot->stamp = ++ctx->depth_stamp;
+    ME_HIP(hipEventRecord(slot->produced, ctx->stream));
+    slot->has_produced = true;
+}
+}  // namespace
+
 #define ME_API_BEGIN(ctx)                                                      \
     if (!(ctx)) return ME_ERR_BAD_ARG;                                         \
     try {                                                                      \
@@ -197,6 +276,17 @@ int32_t me_ctx_create(int32_t device_id, int32_t dtype, const me_model_config* c
         ME_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
         ME_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        {
+            // the output stream's launches are few and short (0.7 ms of kernels per image beside a 22 ms depth step): at the
+            // highest priority they take the first CUs a boundary of the main stream's persistent kernels frees, and the host
+            // thread that waits for their counts and copies waits less
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&ctx->out_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+                (void)hipGetLastError();
+                ME_HIP(hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
+            }
+        }
         ME_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         ME_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         ME_HIP(hipMalloc((void**)&ctx->status_dev, 256));
@@ -224,6 +314,7 @@ void me_ctx_destroy(me_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    if (ctx->out_stream) (void)hipStreamSynchronize(ctx->out_stream);
     ctx->drop_graph();
     // the status word of this context may be the calling thread's current one (ME_API_BEGIN): not after this
     if (me::current_status_word() == ctx->status_dev) me::set_current_status_word(nullptr);
@@ -239,6 +330,11 @@ void me_ctx_destroy(me_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
+    for (me_ctx::DepthSlot& d : ctx->depth_slots) {
+        if (d.produced) (void)hipEventDestroy(d.produced);
+        if (d.consumed) (void)hipEventDestroy(d.consumed);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -264,6 +360,16 @@ int32_t me_ctx_set_stream(me_ctx* ctx, void* hip_stream) {
 int32_t me_ctx_synchronize(me_ctx* ctx) {
     ME_API_BEGIN(ctx)
     ME_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->output_overlap && ctx->out_stream) ME_HIP(hipStreamSynchronize(ctx->out_stream));
+    ME_API_END(ctx)
+}
+
+int32_t me_ctx_set_output_overlap(me_ctx* ctx, int32_t on) {
+    ME_API_BEGIN(ctx)
+    ME_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->out_stream) ME_HIP(hipStreamSynchronize(ctx->out_stream));
+    ctx->output_overlap = on != 0 && ctx->out_stream != nullptr;
+    for (me_ctx::DepthSlot& d : ctx->depth_slots) d.base = nullptr, d.bytes = 0, d.has_produced = d.has_consumed = false;
     ME_API_END(ctx)
 }
 
@@ -733,6 +839,8 @@ int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const flo
     check_pending_status(ctx);
     const bool in_dev = is_device_ptr(img);
     const float* img_dev = (const float*)to_device(ctx, img, (size_t)batch * 3 * S * S * 4, "io.img");
+    const size_t depth_bytes = (size_t)batch * S * S * 4;
+    if (is_device_ptr(inverse_depth)) wait_for_consumers(ctx, inverse_depth, depth_bytes);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (in_dev)
             run_step(ctx, 0, img_dev, batch, f_norm, inverse_depth, fov_deg_out);
@@ -742,6 +850,7 @@ int32_t me_extract_depth(me_ctx* ctx, const float* img, int32_t batch, const flo
         // checked here, and a step whose fused LayerNorm exchange timed out is run once more without the fusion
         if (is_device_ptr(inverse_depth) || !settle_host_result(ctx, attempt == 0)) break;
     }
+    if (is_device_ptr(inverse_depth)) mark_produced(ctx, inverse_depth, depth_bytes);
     ME_API_END(ctx)
 }
 
@@ -756,6 +865,8 @@ int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, cons
     check_pending_status(ctx);
     const bool in_dev = is_device_ptr(rgb);
     const void* src = to_device(ctx, rgb, npix * 3, "io.rgb");
+    const size_t depth_bytes = (size_t)batch * S * S * 4;
+    if (is_device_ptr(inverse_depth)) wait_for_consumers(ctx, inverse_depth, depth_bytes);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (in_dev)
             run_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
@@ -763,6 +874,7 @@ int32_t me_extract_depth_u8(me_ctx* ctx, const uint8_t* rgb, int32_t batch, cons
             enqueue_step(ctx, 1, src, batch, f_norm, inverse_depth, fov_deg_out);
         if (is_device_ptr(inverse_depth) || !settle_host_result(ctx, attempt == 0)) break;
     }
+    if (is_device_ptr(inverse_depth)) mark_produced(ctx, inverse_depth, depth_bytes);
     ME_API_END(ctx)
 }
 
@@ -778,6 +890,7 @@ int64_t me_graph_launch_count(const me_ctx* ctx) { return ctx ? ctx->graph_launc
 int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* min_out,
                               float* max_out) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(depth && count > 0, ME_ERR_BAD_ARG, "me_depth_clamp_minmax: bad argument");
     const bool dev = is_device_ptr(depth);
     float* d = dev ? depth : (float*)site_buf(ctx, "out.depth", (size_t)count * 4);
@@ -795,6 +908,7 @@ int32_t me_depth_clamp_minmax(me_ctx* ctx, float* depth, int64_t count, float* m
 
 int32_t me_depth_clamp_minmax_async(me_ctx* ctx, float* depth, int64_t count, float* minmax_dev) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(depth && minmax_dev && count > 0, ME_ERR_BAD_ARG, "me_depth_clamp_minmax_async: bad argument");
     ME_CHECK(is_device_ptr(depth) && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG,
              "me_depth_clamp_minmax_async: depth and minmax_dev must be device memory");
@@ -831,6 +945,7 @@ int32_t me_stereogram(me_ctx* ctx, const float* depth, int32_t rows, int32_t col
                       float max_depth, int32_t out_w, int32_t out_h, float amplitude,
                       const uint8_t* noise, uint8_t* out) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     stereogram_impl(ctx, depth, rows, cols, min_depth, max_depth, nullptr, out_w, out_h, amplitude, noise, out);
     ME_API_END(ctx)
 }
@@ -839,6 +954,7 @@ int32_t me_stereogram_dev_range(me_ctx* ctx, const float* depth, int32_t rows, i
                                 const float* minmax_dev, int32_t out_w, int32_t out_h, float amplitude,
                                 const uint8_t* noise, uint8_t* out) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(minmax_dev && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG, "me_stereogram_dev_range: minmax_dev");
     stereogram_impl(ctx, depth, rows, cols, 0.f, 0.f, minmax_dev, out_w, out_h, amplitude, noise, out);
     ME_API_END(ctx)
@@ -847,6 +963,7 @@ int32_t me_stereogram_dev_range(me_ctx* ctx, const float* depth, int32_t rows, i
 int32_t me_depthmap_rgb(me_ctx* ctx, const float* depth, int64_t count, float min_depth,
                         float max_depth, uint8_t* rgb) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     depthmap_rgb_impl(ctx, depth, count, min_depth, max_depth, nullptr, rgb);
     ME_API_END(ctx)
 }
@@ -854,6 +971,7 @@ int32_t me_depthmap_rgb(me_ctx* ctx, const float* depth, int64_t count, float mi
 int32_t me_depthmap_rgb_dev_range(me_ctx* ctx, const float* depth, int64_t count, const float* minmax_dev,
                                   uint8_t* rgb) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(minmax_dev && is_device_ptr(minmax_dev), ME_ERR_BAD_ARG, "me_depthmap_rgb_dev_range: minmax_dev");
     depthmap_rgb_impl(ctx, depth, count, 0.f, 0.f, minmax_dev, rgb);
     ME_API_END(ctx)
@@ -862,6 +980,7 @@ int32_t me_depthmap_rgb_dev_range(me_ctx* ctx, const float* depth, int64_t count
 int32_t me_mesh_index(me_ctx* ctx, const float* depth, int32_t width, int32_t height,
                       int32_t* vertex_index, int64_t* nvertices, int64_t* nfaces, int32_t* faces) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(depth && vertex_index && nvertices && nfaces, ME_ERR_BAD_ARG,
              "me_mesh_index: null pointer");
     ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "me_mesh_index: %dx%d", width, height);
@@ -886,6 +1005,7 @@ int32_t me_mesh_vertices(me_ctx* ctx, const float* depth, int32_t width, int32_t
                          const int32_t* vertex_index, int64_t nvertices, uint32_t original_width,
                          uint32_t original_height, float* uv, float* xyz) {
     ME_API_BEGIN(ctx)
+    OutputScope out_scope(ctx, depth);
     ME_CHECK(depth && vertex_index && nvertices >= 0, ME_ERR_BAD_ARG, "me_mesh_vertices: bad argument");
     ME_CHECK(original_width > 0 && original_height > 0, ME_ERR_BAD_ARG, "original size 0");
     const size_t nv = (size_t)width * height;

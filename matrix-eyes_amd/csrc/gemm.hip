@@ -299,11 +299,29 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                 amode == A_PLAIN ? "plain" : "conv", kEpi[epi], p.M, p.N, p.K, p.KH, p.KW, p.stride, gemm_config_name(cfg),
                 p.res32 != nullptr, p.out32 != nullptr, p.out16 != nullptr, p.out16_border, (int)p.lo_off16, (int)p.hi2_off16,
                 p.ln_out16 != nullptr);
+    // algorithmic bytes of the launch (every operand once): what an HBM-bound launch is priced against in bench.py's
+    // kernels[] (the MFMA fraction misstates the residual launches and the ConvTransposes)
+    double launch_bytes = 0.0;
+    {
+        const double MN = (double)p.M * p.N;
+        launch_bytes += amode == A_PLAIN ? (double)p.M * p.K * 2                                              // activation rows
+                                         : (double)p.M * (p.stride > 0 ? p.stride * p.stride : 1) * p.Cin * 2;  // input pixels, once
+        launch_bytes += (double)p.N * p.K * 2;
+        if (epi == EPI_HEAD_FINAL) launch_bytes += (double)p.M * 4;
+        else {
+            if (p.out16) launch_bytes += MN * 2 * (1 + (p.lo_off16 ? 1 : 0) + (p.hi2_off16 ? 1 : 0));
+            if (p.out32) launch_bytes += MN * 4;
+            if (p.res32) launch_bytes += MN * 4;
+            if (p.res32b) launch_bytes += MN * 4;
+            if (p.ln_out16) launch_bytes += p.out8 ? MN : MN * 2;
+            else if (p.out8) launch_bytes += MN;
+        }
+    }
     ProfScope prof(stream,
                    std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + "," +
                        (head_halo ? "12x16px-x32/8w-halo" : (epi == EPI_HEAD_FINAL ? "256x32x64/4w" : gemm_config_name(cfg))) + "," +
                        (amode == A_PLAIN ? "plain" : "conv") + "," + kEpi[epi] + ">",
-                   2.0 * (p.flop_rows ? p.flop_rows : p.M) * p.N * (p.flop_k ? p.flop_k : p.K), 0.0);
+                   2.0 * (p.flop_rows ? p.flop_rows : p.M) * p.N * (p.flop_k ? p.flop_k : p.K), launch_bytes);
     if (head_halo) {
         head_final_halo_launch(p, dtype, stream);
         return;

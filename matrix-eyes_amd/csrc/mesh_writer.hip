@@ -314,6 +314,9 @@ extern "C" int32_t me_ctx_set_write_behind(me_ctx* ctx, int32_t files_in_flight)
 extern "C" int32_t me_output_flush(me_ctx* ctx) {
     if (!ctx) return ME_ERR_BAD_ARG;
     int32_t rc = ME_OK;
+    // (output overlap: the output stream's queued kernels and copies too)
+    if (ctx->output_overlap && ctx->out_stream && hipStreamSynchronize(ctx->out_stream) != hipSuccess)
+        ctx->last_error = "me_output_flush: the output stream failed", rc = ME_ERR_HIP;
     for (int k = 0; k < (int)ctx->write_slots.size(); ++k) {
         try {
             join_pending_write(ctx, k);
@@ -343,6 +346,7 @@ extern "C" int32_t me_mesh_obj_text(me_ctx* ctx, const float* depth, int32_t wid
                  "vertex mode %d", vertex_mode);
         ME_CHECK(width >= 2 && height >= 2, ME_ERR_BAD_SHAPE, "me_mesh_obj_text: %dx%d", width, height);
         ME_CHECK(original_width > 0 && original_height > 0, ME_ERR_BAD_ARG, "original size 0");
+        OutputScope out_scope(ctx, depth);
         const DeviceMesh m = build_mesh(ctx, depth, width, height, original_width, original_height);
         const DeviceText t = obj_text_on_device(ctx, m, width, height, stem, vertex_mode, vertex_colors);
         ME_HIP(hipStreamSynchronize(ctx->stream));
@@ -375,6 +379,7 @@ extern "C" int32_t me_output_mesh(me_ctx* ctx, const float* depth, int32_t width
         ME_CHECK(ply || obj, ME_ERR_BAD_ARG, "mesh destination must end in .obj or .ply: %s",
                  destination_path);
         const bool with_color = vertex_mode == ME_VERTEX_COLOR && vertex_colors;
+        OutputScope out_scope(ctx, depth);
         const auto t_entry = std::chrono::steady_clock::now();
         if (ctx->write_behind && obj) {
             // Before any GPU work of this call: the pinned buffer it will use must be free, and a failed earlier write

@@ -184,6 +184,25 @@ struct me_ctx {
     double mesh_ms[4] = {0, 0, 0, 0};
     int64_t mesh_bytes = 0;
 
+    // Output overlap (me_ctx_set_output_overlap; BASELINE configs[4]: depth -> stereogram -> mesh per image, many images):
+    // the output back end's kernels, copies and their host waits run on `out_stream`, ordered behind the extract_depth step
+    // that PRODUCED the depth buffer they read -- not behind whatever the caller has queued on the main stream since -- so
+    // image i + 1's depth step runs on the GPU while the host waits for image i's mesh counts, text and D2H copy.  A depth
+    // buffer is known by its address range: the step that writes it records `produced` behind itself, every output call
+    // on a buffer leaves `consumed` behind itself, and the next step that writes the range waits for that (the caller
+    // alternates two buffers).  api.hip OutputScope.
+    bool output_overlap = false;
+    hipStream_t out_stream = nullptr;
+    struct DepthSlot {
+        const char* base = nullptr;
+        size_t bytes = 0;
+        hipEvent_t produced = nullptr, consumed = nullptr;
+        bool has_produced = false, has_consumed = false;
+        uint64_t stamp = 0;
+    };
+    DepthSlot depth_slots[4];
+    uint64_t depth_stamp = 0;
+
     // persistent workspaces keyed by site name (no aliasing: zero borders stay zero)
     std::map<std::string, me::DevBuf> bufs;
 
@@ -291,6 +310,19 @@ void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev);
 void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
 
 void report(me_ctx* ctx, float pos, const char* msg);
+
+// Scope of one output back-end entry point (api.hip): with output overlap on, the context's stream is the output stream
+// for the duration of the call, behind the step that produced `depth`; on exit the buffer's `consumed` event is left.
+struct OutputScope {
+    me_ctx* ctx;
+    hipStream_t saved = nullptr;
+    int slot = -1;
+    bool active = false;
+    OutputScope(me_ctx* c, const void* depth);
+    ~OutputScope();
+    OutputScope(const OutputScope&) = delete;
+    OutputScope& operator=(const OutputScope&) = delete;
+};
 
 // calibrate.hip: the two fixed loops of bench.py's calibration leg (out[6])
 void calibrate(me_ctx* ctx, double* out);

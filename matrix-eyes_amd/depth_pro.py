@@ -112,6 +112,12 @@ class Context:
         self._check(self.lib.me_last_mesh_timing(self._h, ms, C.byref(n)))
         return {"mesh_ms": ms[0], "format_ms": ms[1], "d2h_ms": ms[2], "file_ms": ms[3], "bytes": int(n.value)}
 
+    def set_output_overlap(self, on=True):
+        """The output back end on a second stream, ordered behind the extract_depth call that wrote the depth buffer it
+        reads (matrix_eyes_hip.h me_ctx_set_output_overlap): queue image i + 1's extract_depth, then make image i's
+        DeviceDepthMap calls."""
+        self._check(self.lib.me_ctx_set_output_overlap(self._h, 1 if on else 0))
+
     def set_write_behind(self, files_in_flight=2):
         """OBJ files written by host threads behind the caller, up to `files_in_flight` at a time; 0 / False: the
         synchronous form (matrix_eyes_hip.h me_ctx_set_write_behind)."""

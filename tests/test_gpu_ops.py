@@ -382,6 +382,33 @@ def test_attention_prescaled(dtype, tokens, windows, heads):
     assert rel_l2(out.float(), ref) < 1.5 * OUT_EPS[dtype]
 
 
+def test_attention_prescaled_token_counts():
+    """The forward pass's kernel over the query-block geometry: workgroups of six waves x 32 queries, the one query beyond the
+    whole blocks (tokens = 32 n + 1: 33, 65, 193, 577, 609) on the trailing workgroups' vector-pipe path
+    (attention_extra_query), every other remainder as one more partly filled block; key tiles with 1 to 64 valid rows;
+    a guard row behind the output stays untouched."""
+    ctx = ctx_for("tiny", "f16")
+    for tokens in [1, 2, 31, 32, 33, 34, 63, 64, 65, 66, 97, 129, 191, 192, 193, 194, 225, 257, 385, 576, 577, 578, 609, 641]:
+        windows, heads = (3, 2) if tokens < 400 else (2, 1)
+        C = heads * 64
+        g = torch.Generator().manual_seed(1000 + tokens)
+        x = torch.randn(windows * tokens, 3 * C, generator=g) * 1.5
+        x[:, :C] *= QSCALE
+        qkv = dev16(x, "f16")
+        out = torch.full((windows * tokens + 1, C), 7.0, dtype=torch.float16, device="cuda")
+        _check(ctx, ctx.lib.me_op_attention_prescaled(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+        ctx.synchronize()
+        xx = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        q, k, v = xx[0], xx[1], xx[2]
+        ref = (torch.softmax((q @ k.transpose(3, 2)) * math.log(2.0), dim=3) @ v).transpose(1, 2).reshape(windows * tokens, C)
+        assert bool((out[windows * tokens] == 7.0).all()), tokens
+        assert max_err_over_max(out[:-1].float(), ref) < 2 * OUT_EPS["f16"], tokens
+        assert rel_l2(out[:-1].float(), ref) < 1.5 * OUT_EPS["f16"], tokens
+        # the last query of every window on its own (the vector-pipe path when tokens = 32 n + 1)
+        last = out[:-1].float().reshape(windows, tokens, C)[:, -1]
+        assert rel_l2(last, ref.reshape(windows, tokens, C)[:, -1]) < 2 * OUT_EPS["f16"], tokens
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_running_max_branches(dtype):
     """The rescale branch of both kernels (cdna_hip_programming.md rule 26: a rare data-dependent branch needs an input

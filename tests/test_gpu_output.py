@@ -380,6 +380,79 @@ def test_config4_chain_batch_of_eight(tmp_path):
         (tmp_path / f"mesh{b}.obj").unlink()               # 0.6 - 1.3 GB of text on the test box's tmpfs
 
 
+def test_config4_chain_pipelined_across_images(tmp_path):
+    """bench.py --chain's pipelined form (me_ctx_set_output_overlap) -- image i + 1's me_extract_depth
+    is queued BEFORE image i's DepthMap::new / stereogram / OBJ calls, which run on the context's output stream behind the
+    step that wrote their depth buffer; two depth buffers in turn, OBJ files written behind the caller.  Four different
+    images: every stereogram and every OBJ + MTL is byte for byte what the serial, synchronised order produces, the depth
+    buffers hold the clamped maps of the LAST two images (nothing overwrote a buffer that was still being read), and the
+    serial products themselves are the oracle's for one image."""
+    import filecmp
+    import torch
+    from matrix_eyes_amd.synthetic import synthetic_images
+    from util import loaded_ctx
+    ctx = loaded_ctx("full", "f16")
+    S, N = ctx.cfg.img_size, 4
+    rgbs = [torch.from_numpy(synthetic_images(1, S, "structured", seed=900 + i)).cuda() for i in range(N)]
+    noise = np.random.default_rng(99).integers(0, 256, size=(S, S, 3), dtype=np.uint8)
+    noise_dev = torch.from_numpy(noise).cuda()
+    bufs = [torch.empty(1, S, S, dtype=torch.float32, device="cuda") for _ in range(2)]
+
+    for tag in ("serial", "piped"):
+        (tmp_path / tag).mkdir()
+
+    def outputs(i, tag, stereos, clamped):
+        dm = m.DeviceDepthMap(ctx, bufs[i & 1][0], (S, S))
+        stereos.append(dm.stereogram(1.0 / 16.0, noise_dev))
+        # (the same file name in both runs: the OBJ's first line names its .mtl after the file's stem)
+        dm.output_mesh(str(tmp_path / tag / f"mesh{i}.obj"), f"photo{i}.jpg", m.VertexMode.Texture)
+        clamped.append(dm)
+
+    # serial: every step synchronised before the next begins
+    serial_stereo, serial_maps, raw0 = [], [], None
+    for i in range(N):
+        ctx.extract_depth(rgbs[i], None, out=bufs[i & 1])
+        ctx.synchronize()
+        if i == 0:
+            raw0 = bufs[0][0].cpu().numpy().copy()
+        outputs(i, "serial", serial_stereo, serial_maps)
+        ctx.synchronize()
+    serial_stereo = [t.cpu().numpy() for t in serial_stereo]
+    serial_last = [bufs[k][0].cpu().numpy().copy() for k in range(2)]
+    # pipelined
+    ctx.set_output_overlap(True)
+    ctx.set_write_behind(2)
+    try:
+        piped_stereo, piped_maps = [], []
+        ctx.extract_depth(rgbs[0], None, out=bufs[0])
+        for i in range(N):
+            if i + 1 < N:
+                ctx.extract_depth(rgbs[i + 1], None, out=bufs[(i + 1) & 1])
+            outputs(i, "piped", piped_stereo, piped_maps)
+        ctx.output_flush()
+        ctx.synchronize()
+    finally:
+        ctx.set_write_behind(0)
+        ctx.set_output_overlap(False)
+    assert ctx.status_flags() == 0
+    for i in range(N):
+        assert np.array_equal(piped_stereo[i].cpu().numpy(), serial_stereo[i]), i
+        assert filecmp.cmp(tmp_path / "piped" / f"mesh{i}.obj", tmp_path / "serial" / f"mesh{i}.obj", shallow=False), i
+        assert (tmp_path / "piped" / f"mesh{i}.mtl").read_text() == OO.mtl_text(f"photo{i}.jpg")
+    for k in range(2):
+        assert np.array_equal(bufs[k][0].cpu().numpy(), serial_last[k])
+    assert len({t.tobytes() for t in serial_stereo}) == N           # four different images
+    # the serial products are the oracle's (image 0)
+    od, mn, mx = OO.clamp_minmax(raw0)
+    assert np.array_equal(serial_stereo[0], OO.stereogram(od, mn, mx, S, S, 1.0 / 16.0, noise))
+    vi, nv, faces = OO.mesh_index(od)
+    uv, xyz = OO.mesh_vertices(od, vi, nv, (S, S))
+    OO.write_obj(str(tmp_path / "oracle0.obj"), uv, xyz, faces, "texture", "mesh0")
+    assert filecmp.cmp(tmp_path / "serial" / "mesh0.obj", tmp_path / "oracle0.obj", shallow=False)
+    for f in tmp_path.rglob("*.obj"):
+        f.unlink()
+
+
 def test_device_number_formatter_prints_like_rust():
     """obj_format.hip's digit generator on the GPU (64 x 128-bit multiplications by __umul64hi, tables in device
     memory) against the oracle's rust_display_f64 (the shortest round-trip digits of CPython's repr laid out positionally): random

@@ -21,10 +21,11 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
     ("v1 (round 1 kernel)", {"ME_ATT_V": "1"}, False),
-    ("v2 side by side, 3 waves", {"ME_ATT_HALVES": "0"}, True),
-    ("v2 halves, 4 waves", {"ME_ATT_HALVES": "1"}, True),
+    ("v2 4 waves x 32 q (round 4)", {"ME_ATT_NW": "4"}, True),
+    ("v2 6 waves x 32 q + extra query", {"ME_ATT_NW": "6"}, True),
+    ("v2 6 waves, halves (4 per SIMD)", {"ME_ATT_NW": "6", "ME_ATT_HALVES": "1"}, True),
 ]
-KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES")
+KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES", "ME_ATT_NW")
 
 
 def run(env, pre):
