@@ -832,7 +832,12 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
              "attention: grid too large");
     const int nqb = (tokens + 127) / 128, ngroups = windows * heads;
     const dim3 grid(8 * nqb * ((ngroups + 7) / 8));
-    ProfScope prof(stream, "attention_kernel", 4.0 * windows * heads * (double)tokens * tokens * 64, 0.0);
+    // ME_ATT_V=2 (development): round 4's attention2_kernel for a pre-scaled Q instead of attention3.hip's (tools/attn_ab.py)
+    const char* av = getenv("ME_ATT_V");
+    const bool use_v2 = av && atoi(av) == 2;
+    ProfScope prof(stream, !q_prescaled ? "attention_kernel" : (use_v2 ? "attention2_kernel" : "attention3_kernel"),
+                   4.0 * windows * heads * (double)tokens * tokens * 64,
+                   (double)windows * tokens * heads * 64 * (out8 ? 7.03 : 8.0));  // q, k, v read once + the output
     // scale = 1/sqrt(64) (vit.rs:47), folded with log2(e) so the softmax runs on exp2
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (q_prescaled) {
@@ -840,6 +845,10 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
         // reference point is the exact running maximum (tools/attn_ab.py compares the two)
         const char* th = getenv("ME_ATT_THR");
         const float defer_thr = th ? (float)atof(th) : 8.0f;
+        if (!use_v2) {
+            attention3_launch(qkv, out, windows, tokens, heads, dtype, stream, segs, out8, out8_scale, out8_mt, defer_thr);
+            return;
+        }
         // Two forms (HALVES above), within 1.5 % of each other from 37 to 296 windows (profiles/r04_attention_ablations.txt:
         // three waves per SIMD with the leaner tile against four with the vector-pipe row sums).  ONE form runs at every
         // size -- their row sums round differently, and a batch must equal a loop of batch-one calls bit for bit;

@@ -320,6 +320,10 @@ struct RowSegs {
 void attention_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads,
                       int32_t dtype, hipStream_t stream, const RowSegs* segs = nullptr, uint8_t* out8 = nullptr,
                       uint8_t* out8_scale = nullptr, int64_t out8_mt = 0, bool q_prescaled = false);
+// attention3.hip: the kernel attention_launch runs for a pre-scaled Q (48 queries per wave on 16x16x32 MFMAs, the query beyond
+// whole wave units on the vector pipe)
+void attention3_launch(const void* qkv, void* out, int32_t windows, int32_t tokens, int32_t heads, int32_t dtype, hipStream_t stream,
+                       const RowSegs& segs, uint8_t* out8, uint8_t* out8_scale, int64_t out8_mt, float defer_thr);
 // 1/sqrt(head_dim) (vit.rs:47) times log2(e): the factor a pre-scaled Q carries (GemmParams::qscale of the qkv launch)
 constexpr float kAttnQScale = 0.125f * 1.44269504088896340736f;
 

@@ -20,12 +20,11 @@ out = torch.empty(M, 1024, dtype=torch.float16, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
-    ("v1 (round 1 kernel)", {"ME_ATT_V": "1"}, False),
-    ("v2 4 waves x 32 q (round 4)", {"ME_ATT_NW": "4"}, True),
-    ("v2 6 waves x 32 q + extra query", {"ME_ATT_NW": "6"}, True),
-    ("v2 6 waves, halves (4 per SIMD)", {"ME_ATT_NW": "6", "ME_ATT_HALVES": "1"}, True),
+    ("v1 (round 1 kernel)", {}, False),
+    ("v2 4 waves x 32 q (round 4)", {"ME_ATT_V": "2"}, True),
+    ("v3 4 waves x 48 q + extra query", {}, True),
 ]
-KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES", "ME_ATT_NW")
+KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES")
 
 
 def run(env, pre):
