@@ -129,7 +129,9 @@ def kernel_row(k, steps):
     return {"kernel": k["kernel"], "launches_per_step": k["launches"] / steps, "ms_per_step": round(k["total_ms"] / steps, 4),
             "tflops": None if tf is None else round(tf, 1), "mfma_frac": None if mf is None else round(mf, 3),
             "algorithmic_gbs": None if gbs is None else round(gbs, 0), "hbm_frac": None if hf is None else round(hf, 3),
-            "bound": None if (mf is None and hf is None) else ("hbm" if (hf or 0) > (mf or 0) else "mfma")}
+            # nearer which roof: "hbm" where the byte fraction is the larger one and at least 0.3 (a launch at a quarter of
+            # both roofs -- attention, whose K and V are re-read from L2, not from HBM -- is short of neither by its bytes)
+            "bound": None if (mf is None and hf is None) else ("hbm" if (hf or 0) > (mf or 0) and (hf or 0) >= 0.3 else "mfma")}
 
 
 def calibration_object(cal, value):

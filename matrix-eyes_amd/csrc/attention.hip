@@ -832,9 +832,12 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
              "attention: grid too large");
     const int nqb = (tokens + 127) / 128, ngroups = windows * heads;
     const dim3 grid(8 * nqb * ((ngroups + 7) / 8));
-    // ME_ATT_V=2 (development): round 4's attention2_kernel for a pre-scaled Q instead of attention3.hip's (tools/attn_ab.py)
+    // ME_ATT_V=3 (development, tools/attn_ab.py): round 5's re-cut (attention3.hip: 48 queries per wave on 16x16x32 MFMAs, three
+    // workgroups per (window, head), persistent, the 577th query on the vector pipe) instead of attention2_kernel.  Measured
+    // equal stand-alone and slower in the step (profiles/r05_attention_recut_ab.txt), so attention2_kernel stays the forward
+    // pass's kernel.
     const char* av = getenv("ME_ATT_V");
-    const bool use_v2 = av && atoi(av) == 2;
+    const bool use_v2 = !(av && atoi(av) == 3);
     ProfScope prof(stream, !q_prescaled ? "attention_kernel" : (use_v2 ? "attention2_kernel" : "attention3_kernel"),
                    4.0 * windows * heads * (double)tokens * tokens * 64,
                    (double)windows * tokens * heads * 64 * (out8 ? 7.03 : 8.0));  // q, k, v read once + the output

@@ -410,6 +410,43 @@ def test_attention_prescaled_token_counts():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_attention3_recut_kernel(dtype, monkeypatch):
+    """Round 5's re-cut of the forward pass's attention (csrc/attention3.hip, ME_ATT_V=3: 48 queries per wave on 16x16x32 MFMAs,
+    persistent workgroups over 192-query items, the query beyond whole wave units on the vector pipe).  It lost its A/B in the
+    step (profiles/r05_attention_recut_ab.txt) and is not the default; it stays selectable, so it stays tested: the geometry
+    sweep of test_attention_prescaled_token_counts' kind against fp64, more items than resident workgroups (items > grid via
+    ME_ATT_GRID=8), and agreement with attention2_kernel to the rounding of the 16-bit output."""
+    ctx = ctx_for("tiny", dtype)
+    for tokens, windows, heads, grid in [(577, 3, 2, 0), (577, 2, 16, 8), (65, 5, 2, 0), (49, 3, 1, 8), (97, 2, 2, 0), (48, 2, 1, 0),
+                                         (1, 3, 1, 0), (193, 2, 2, 8), (640, 1, 1, 0), (641, 1, 2, 0)]:
+        C = heads * 64
+        g = torch.Generator().manual_seed(7000 + tokens + heads)
+        x = torch.randn(windows * tokens, 3 * C, generator=g) * 1.5
+        x[:, :C] *= QSCALE
+        qkv = dev16(x, dtype)
+        outs = {}
+        for v in ("2", "3"):
+            monkeypatch.setenv("ME_ATT_V", v)
+            if grid:
+                monkeypatch.setenv("ME_ATT_GRID", str(grid))
+            else:
+                monkeypatch.delenv("ME_ATT_GRID", raising=False)
+            out = torch.full((windows * tokens + 1, C), 7.0, dtype=TORCH16[dtype], device="cuda")
+            _check(ctx, ctx.lib.me_op_attention_prescaled(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+            ctx.synchronize()
+            assert bool((out[windows * tokens] == 7.0).all()), (tokens, v)
+            outs[v] = out[:-1].float()
+        xx = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        q, k, v_ = xx[0], xx[1], xx[2]
+        ref = (torch.softmax((q @ k.transpose(3, 2)) * math.log(2.0), dim=3) @ v_).transpose(1, 2).reshape(windows * tokens, C)
+        assert max_err_over_max(outs["3"], ref) < 2 * OUT_EPS[dtype], tokens
+        assert rel_l2(outs["3"], ref) < 1.5 * OUT_EPS[dtype], tokens
+        assert rel_l2(outs["3"], outs["2"]) < 1.5 * OUT_EPS[dtype], tokens
+    monkeypatch.delenv("ME_ATT_V", raising=False)
+    monkeypatch.delenv("ME_ATT_GRID", raising=False)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_running_max_branches(dtype):
     """The rescale branch of both kernels (cdna_hip_programming.md rule 26: a rare data-dependent branch needs an input
     that forces it): keys that dominate their query are planted in EVERY 64-key tile with growing scores (8 natural

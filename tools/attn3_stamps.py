@@ -4,6 +4,7 @@ import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import matrix_eyes_amd as m
+os.environ["ME_ATT_V"] = "3"
 ctx = m.Context(0, "f16", m.ModelConfig.tiny())
 lib, h = ctx.lib, ctx.handle
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
@@ -38,4 +39,5 @@ print(f"== attention3_kernel, {W} windows: {us:.1f} us = {FLOP / us / 1e6:.0f} T
 for i, nm in enumerate(NAMES):
     print(f"  {nm:24s} mean {a[:, i].mean():9.0f} clocks per wave  ({a[:, i].mean() / 9.0:7.0f} per tile)  share {a[:, i].sum() / a[:, 6].sum():.3f}")
 print(f"  prologue (to first tile)  mean {a[:, 7].mean():9.0f} clocks per wave;  unaccounted (prologue, tail key, store stage) share {1 - a[:, :6].sum() / a[:, 6].sum():.3f}")
+print(f"  (per-wave numbers are sums over the items a persistent workgroup took)")
 print(f"  wave lifetime: min {a[:, 6].min():.0f}  median {np.median(a[:, 6]):.0f}  max {a[:, 6].max():.0f} clocks")

@@ -21,8 +21,8 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
     ("v1 (round 1 kernel)", {}, False),
-    ("v2 4 waves x 32 q (round 4)", {"ME_ATT_V": "2"}, True),
-    ("v3 4 waves x 48 q + extra query", {}, True),
+    ("v2 4 waves x 32 q (round 4, the product)", {}, True),
+    ("v3 4 waves x 48 q, persistent (ME_ATT_V=3)", {"ME_ATT_V": "3"}, True),
 ]
 KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES")
 

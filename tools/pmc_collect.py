@@ -62,7 +62,7 @@ def describe(op, cfg):
     if op == "conv768":   # 16-bit bordered input, weights, f32 residual in, f32 + 16-bit out
         px = 768 * 768
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},conv,store>", 770 * 770 * 256 * 2 + 256 * 2304 * 2 + px * 256 * (4 + 4 + 2)
-    return "attention3_kernel", 35 * 577 * (3072 + 1024) * 2
+    return "attention2_kernel", 35 * 577 * (3072 + 1024) * 2
 KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_kernel", "gemm_8ph_kernel", "conv_halo_kernel",
                "attention_kernel", "attention2_kernel", "attention3_kernel")
 
