@@ -808,6 +808,303 @@ __global__ __launch_bounds__(256, MINW) void attention2_kernel(const T* __restri
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// attention2_kernel with the score MFMAs of tile t + 1 issued in front of the softmax of tile t (round 5; ME_ATT_V=4).
+// Same decomposition, operands, arithmetic and results as attention2_kernel; what changes is the order inside a wave: the
+// round-4 kernel's tile is a serial chain K reads -> 8 MFMAs -> max -> 32 exponentials -> 12 MFMAs, and the phase clocks showed
+// co-resident waves interleaving such chains at 40 % of what the matrix and vector pipes could issue.  Here a wave holds TWO
+// score blocks: while the vector pipe works through exp / cvt of tile t the matrix pipe already has S'(t + 1) = K(t + 1) Qc^T - m'
+// to do, from the same wave's instruction stream (cross-tile software pipelining; the deferred maximum makes it legal: when the
+// reference point does move in tile t, the block computed ahead is corrected by the same delta).  Costs 32 registers (200: two
+// waves per SIMD) and a third ring slot (K of tile t + 1 is read while V of tile t is, and tile t + 2 is in flight).
+template <typename T, int MINW>
+__global__ __launch_bounds__(256, MINW) void attention2p_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads,
+                                                             int ngroups, RowSegs segs, uint8_t* __restrict__ out8,
+                                                             uint8_t* __restrict__ out8_scale, int64_t out8_mt, float defer_thr) {
+    typedef typename Mfma32<T>::frag frag;
+    constexpr int NSLOT = 3;
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * 2 * TILE_BYTES];  // slot: K tile, V tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bid = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int C = heads * 64;
+    const int ldq = 3 * C;
+    const int nqb = (tokens + 127) >> 7;
+    const int xcd = bid & 7, slot0 = bid >> 3;
+    const int group = xcd + 8 * (slot0 / nqb);  // = win * heads + head
+    const int qblk = slot0 - (slot0 / nqb) * nqb;
+    if (group >= ngroups) return;  // uniform: the whole workgroup leaves before any barrier
+    const int win = group / heads, head = group - win * heads;
+    const int q0 = qblk * 128 + wave * 32;
+    int64_t row0 = (int64_t)win * tokens;
+    if (segs.seg1 && win >= segs.win0)
+        row0 = win < segs.win0 + segs.win1 ? segs.seg1 + (int64_t)(win - segs.win0) * tokens
+                                           : segs.seg2 + (int64_t)(win - segs.win0 - segs.win1) * tokens;
+    const T* qbase = qkv + head * 64;
+    const T* kbase = qkv + C + head * 64;
+    const T* vbase = qkv + 2 * C + head * 64;
+    // K/V staging by LDS-DMA (see attention2_kernel): wave w stages pieces 2w and 2w + 1 of K and of V
+    const int st_row = lane >> 3, st_slot = lane & 7;
+    const unsigned row_bytes = (unsigned)ldq * 2u;
+    unsigned koff0, voff0;
+    {
+        const int rr = (2 * wave) * 8 + st_row;
+        koff0 = (unsigned)rr * row_bytes + ((st_slot ^ ((rr >> 1) & 7)) << 4);
+        voff0 = (unsigned)rr * row_bytes + ((st_slot ^ (((rr >> 1) & 1) << 2)) << 4);
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_address(smem));
+    const char* kwin = uniform_ptr((const char*)(kbase + row0 * ldq));
+    const char* vwin = uniform_ptr((const char*)(vbase + row0 * ldq));
+    const int nkt = (tokens + KT - 1) / KT;
+    auto stage = [&](int kt, int slot) {  // 4 LDS-DMA instructions per wave and tile
+        const unsigned dst = smem_base + slot * (2 * TILE_BYTES) + (2 * wave) * 1024;
+        const char* kt_k = uniform_ptr(kwin + (size_t)kt * KT * row_bytes);
+        const char* kt_v = uniform_ptr(vwin + (size_t)kt * KT * row_bytes);
+        if ((kt + 1) * KT <= tokens) {
+            unsigned k0 = koff0, v0 = voff0;
+            asm volatile("" : "+v"(k0), "+v"(v0));
+            glds16_raw(kt_k, k0, dst);
+            glds16_raw(kt_v, v0, dst + TILE_BYTES);
+            glds16_raw(kt_k, (k0 ^ 64u) + 8u * row_bytes, dst + 1024);
+            glds16_raw(kt_v, v0 + 8u * row_bytes, dst + TILE_BYTES + 1024);
+        } else {  // the ragged last tile: rows past the end read the last row (masked or unused below)
+            const int last = tokens - 1 - kt * KT;  // >= 0
+            int sr = st_row, ss = st_slot;
+            asm volatile("" : "+v"(sr), "+v"(ss));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rr = (2 * wave + i) * 8 + sr;
+                const unsigned rowb = (unsigned)(rr < last ? rr : last) * row_bytes;
+                glds16_raw(kt_k, rowb + ((ss ^ ((rr >> 1) & 7)) << 4), dst + i * 1024);
+                glds16_raw(kt_v, rowb + ((ss ^ (((rr >> 1) & 1) << 2)) << 4), dst + TILE_BYTES + i * 1024);
+            }
+        }
+    };
+    const int il = lane & 15;
+    int k_lane, v_lane;
+    {
+        const int k_swz = (r >> 1) & 7;
+        k_lane = r * 128 + ((h ^ k_swz) << 4);
+        const int v_qrow = il >> 2, v_p = il & 3, v_dhalf = (lane >> 4) & 1;
+        v_lane = (4 * h + v_qrow) * 128 + ((2 * v_dhalf + (v_p >> 1)) << 4) + ((v_p & 1) << 3) + (((v_qrow >> 1) & 1) << 6);
+    }
+    f32x16 o[2], lsum, negm;
+    o[0] = f32x16{0};
+    o[1] = f32x16{0};
+    lsum = f32x16{0};
+    negm = f32x16{0};
+    float m_run = 0.f;  // the reference point (exp2 units); negm == -m_run in all sixteen registers
+    frag ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+
+    const bool tail_key = (tokens % KT) == 1 && nkt >= 2;
+    const int nfull = tail_key ? nkt - 1 : nkt;  // tiles that run on the matrix pipe
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+
+    // Q fragments: B operand, lane holds Qc[q0 + r][16 s + 8 h + 0..7], Qc = Q * scale * log2(e)
+    frag qf[4];
+    {
+        int q = q0 + r;
+        q = q < tokens ? q : tokens - 1;
+        const T* qp = qbase + (row0 + q) * ldq + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 t = __builtin_bit_cast(i32x4, qf[s]);
+            asm volatile("" : "+v"(t));
+            qf[s] = __builtin_bit_cast(frag, t);
+        }
+    }
+    const bool active = q0 < tokens;
+
+    // S'(kt) = K(kt) Qc^T - m' from ring slot kt % 3; the ragged last tile's keys past the end become -inf
+    auto scores = [&](int kt, f32x16 (&s)[2]) {
+        unsigned ka = smem_base + (kt % NSLOT) * (2 * TILE_BYTES) + (unsigned)k_lane;
+        asm volatile("" : "+v"(ka));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const frag kf = lds_read_frag<frag>((ka ^ (unsigned)(st << 5)) + ks * 32 * 128);
+                s[ks] = Mfma32<T>::run(kf, qf[st], st == 0 ? negm : s[ks]);
+            }
+        if ((kt + 1) * KT > tokens) {  // uniform: the ragged tile
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int key = kt * KT + ks * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (key >= tokens) s[ks][g] = -INFINITY;
+                }
+        }
+    };
+
+    // tile 0's scores in front of the loop
+    f32x16 sc[2], sn[2];
+    wait_vmcnt<4>();  // tile 0 has landed (tile 1's four requests may still be in flight)
+    if (nkt == 1) wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (active) scores(0, sc);
+    for (int kt = 0; kt < nfull; ++kt) {
+        // tile kt + 1 has landed in every wave's view; the slot of tile kt - 1 is free for tile kt + 2
+        if (kt + 1 < nkt) {
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nkt) stage(kt + 2, (kt + 2) % NSLOT);
+        }
+        if (active) {
+            // ---- the NEXT tile's scores first: the matrix pipe works on them while the vector pipe does this tile's softmax.
+            // (Not in the first tile: its maximum SETS the reference point, and the next block then starts its accumulators
+            // from it like every later one -- computed ahead it would be corrected by a subtraction instead, the same value
+            // to the last rounding but not the same bits as attention2_kernel's.)
+            const bool has_next = kt + 1 < nfull;
+            if (has_next && kt != 0) scores(kt + 1, sn);
+            // ---- does the running maximum grow?
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) mloc = fmaxf(mloc, sc[ks][g]);
+            {
+                float a = mloc, b = mloc;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+                mloc = fmaxf(a, b);
+            }
+            if (kt == 0 || __any(mloc > defer_thr)) {
+                const float delta = kt == 0 ? mloc : fmaxf(mloc, 0.f);
+                if (kt != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) o[0][g] *= alpha, o[1][g] *= alpha, lsum[g] *= alpha;
+                }
+                m_run += delta;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) negm[g] = -m_run;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sc[ks][g] -= delta;
+                if (has_next && kt != 0) {  // the block computed ahead used the old reference point
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) sn[ks][g] -= delta;
+                }
+            }
+            if (has_next && kt == 0) scores(1, sn);
+            // ---- p = exp2(S')
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) sc[ks][g] = __builtin_amdgcn_exp2f(sc[ks][g]);
+            // ---- O^T += V^T P^T,  l += 1^T P^T
+            unsigned va = smem_base + (kt % NSLOT) * (2 * TILE_BYTES) + TILE_BYTES + (unsigned)v_lane;
+            asm volatile("" : "+v"(va));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    frag pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)sc[ks][8 * s2 + j];
+                    lsum = Mfma32<T>::run(ones, pf, lsum);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const unsigned vp = (va ^ (unsigned)(d << 6)) + (ks * 32 + 16 * s2) * 128;
+                        const s16x4 half0 = lds_read_tr16_at(vp), half1 = lds_read_tr16_at(vp + 8 * 128);
+                        typedef short s16x8 __attribute__((__vector_size__(16)));
+                        const s16x8 both = __builtin_shufflevector(half0, half1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[d] = Mfma32<T>::run(__builtin_bit_cast(frag, both), pf, o[d]);
+                    }
+                }
+            sc[0] = sn[0], sc[1] = sn[1];
+        }
+    }
+    float l_tot = lsum[0];
+    if (tail_key) {
+        // 577 = 9 x 64 + 1: the single key of the last tile (row 0 of slot (nkt - 1) % 3; its DMA was waited for and the
+        // workgroup met in the loop's last iteration) as a rank-one update
+        if (active) {
+            const char* kb = smem + ((nkt - 1) % NSLOT) * (2 * TILE_BYTES);
+            const char* vb = kb + TILE_BYTES;
+            float dot = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const frag kf = *reinterpret_cast<const frag*>(kb + ((2 * st + h) << 4));  // row 0: no swizzle
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot = __builtin_fmaf((float)kf[j], (float)qf[st][j], dot);
+            }
+            dot += __shfl_xor(dot, 32);
+            const float rel = dot - m_run;
+            const float delta = fmaxf(rel, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            const float p16 = (float)(T)__builtin_amdgcn_exp2f(rel - delta);
+            l_tot = l_tot * alpha + p16;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    typedef T v4 __attribute__((ext_vector_type(4)));
+                    const v4 vv = *reinterpret_cast<const v4*>(vb + ((4 * d + g4) << 4) + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[d][4 * g4 + e] = __builtin_fmaf(p16, (float)vv[e], o[d][4 * g4 + e] * alpha);
+                }
+        }
+    }
+    // ---- normalise and store (as attention2_kernel)
+    auto round16 = [](float x) -> T {
+        asm volatile("" : "+v"(x));
+        return (T)x;
+    };
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (out8) {
+        const int64_t m = row0 + q;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            float v[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                v[e] = (float)round16(o[d][e] * inv);
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const unsigned sb = mx_scale_byte(amax);
+            const float scl = mx_inv_scale(sb);
+            if (q < tokens) {
+                uint8_t* op = out8 + m * C + head * 64 + d * 32 + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<unsigned*>(op + 8 * g4) =
+                        pack_fp8x4(v[4 * g4] * scl, v[4 * g4 + 1] * scl, v[4 * g4 + 2] * scl, v[4 * g4 + 3] * scl);
+                if (h == 0) out8_scale[a_scale_index(m, head * 2 + d, out8_mt)] = (uint8_t)sb;
+            }
+        }
+    } else if (q < tokens) {
+        T* op = out + (row0 + q) * C + head * 64 + 4 * h;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef T v4 __attribute__((ext_vector_type(4)));
+                v4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round16(o[d][4 * g4 + e] * inv);
+                *reinterpret_cast<v4*>(op + d * 32 + 8 * g4) = v;
+            }
+    }
+}
+
 }  // namespace
 
 #ifdef ME_ATT_STAMPS
@@ -838,6 +1135,7 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
     // pass's kernel.
     const char* av = getenv("ME_ATT_V");
     const bool use_v2 = !(av && atoi(av) == 3);
+    const bool use_pipe = av && atoi(av) == 4;  // attention2p_kernel: the next tile's score MFMAs in front of this tile's softmax
     ProfScope prof(stream, !q_prescaled ? "attention_kernel" : (use_v2 ? "attention2_kernel" : "attention3_kernel"),
                    4.0 * windows * heads * (double)tokens * tokens * 64,
                    (double)windows * tokens * heads * 64 * (out8 ? 7.03 : 8.0));  // q, k, v read once + the output
@@ -850,6 +1148,27 @@ void attention_launch(const void* qkv, void* out, int32_t windows, int32_t token
         const float defer_thr = th ? (float)atof(th) : 8.0f;
         if (!use_v2) {
             attention3_launch(qkv, out, windows, tokens, heads, dtype, stream, segs, out8, out8_scale, out8_mt, defer_thr);
+            return;
+        }
+        if (use_pipe) {
+            const int nqb_p = (tokens + 127) / 128;
+            const dim3 grid_p(8 * nqb_p * ((windows * heads + 7) / 8));
+            const char* mw = getenv("ME_ATT_MINW");  // (development: 2 = 200 registers, no scratch; default 3 = 168 registers, 16 bytes of scratch)
+            const bool two = mw && atoi(mw) == 2;
+#define ME_ATT2P(T, MW)                                                                                                     \
+    hipLaunchKernelGGL((attention2p_kernel<T, MW>), grid_p, dim3(256), 0, stream, (const T*)qkv, (T*)out, tokens, heads, \
+                       windows * heads, segs, out8, out8_scale, out8_mt, defer_thr)
+            if (dtype == ME_DTYPE_F16) {
+                if (two) ME_ATT2P(f16, 2);
+                else ME_ATT2P(f16, 3);
+            } else if (dtype == ME_DTYPE_BF16) {
+                if (two) ME_ATT2P(bf16, 2);
+                else ME_ATT2P(bf16, 3);
+            } else {
+                fail(ME_ERR_BAD_ARG, "attention: bad dtype %d", dtype);
+            }
+#undef ME_ATT2P
+            ME_HIP(hipGetLastError());
             return;
         }
         // Two forms (HALVES above), within 1.5 % of each other from 37 to 296 windows (profiles/r04_attention_ablations.txt:

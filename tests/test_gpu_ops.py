@@ -410,6 +410,53 @@ def test_attention_prescaled_token_counts():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_pipelined_kernel_is_bit_identical(dtype, monkeypatch):
+    """attention2p_kernel (ME_ATT_V=4: tile t + 1's score MFMAs issued in front of tile t's softmax, three ring slots) performs the
+    arithmetic of attention2_kernel in the same order: bit-identical outputs over the token-count geometry (ragged last tiles,
+    the single tail key, one-tile inputs) at two and three waves per SIMD -- as long as the reference point does not move
+    after the first tile.  Where it does (planted dominating keys), the block computed ahead is corrected by a subtraction
+    where attention2_kernel starts its accumulator from the new reference point: the same value to the last rounding, so
+    there the two are held to each other within the output's rounding and both to the fp64 softmax."""
+    ctx = ctx_for("tiny", dtype)
+    for tokens, windows, heads, planted in [(577, 3, 2, False), (65, 5, 2, False), (1, 3, 1, False), (2, 2, 1, False), (63, 2, 2, False),
+                                            (64, 2, 2, False), (66, 2, 1, False), (128, 2, 2, False), (129, 2, 1, False), (130, 2, 1, False),
+                                            (193, 2, 2, False), (300, 2, 1, False), (576, 1, 2, False), (578, 1, 1, False),
+                                            (640, 1, 1, False), (641, 1, 2, False), (577, 2, 16, False), (577, 2, 2, True),
+                                            (300, 2, 1, True), (641, 1, 2, True)]:
+        C = heads * 64
+        g = torch.Generator().manual_seed(9000 + tokens + heads)
+        x = torch.randn(windows * tokens, 3 * C, generator=g) * (1.5 if planted else 1.0)
+        if planted:     # dominating keys in late tiles: the reference point moves after the next block was computed
+            x[tokens // 2 + 70, C:2 * C] *= 6.0
+            x[tokens - 1, C:2 * C] *= 5.0
+        x[:, :C] *= QSCALE
+        qkv = dev16(x, dtype)
+        outs = []
+        for env in ({}, {"ME_ATT_V": "4"}, {"ME_ATT_V": "4", "ME_ATT_MINW": "2"}):
+            for k in ("ME_ATT_V", "ME_ATT_MINW"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out = torch.full((windows * tokens + 1, C), 7.0, dtype=TORCH16[dtype], device="cuda")
+            _check(ctx, ctx.lib.me_op_attention_prescaled(ctx.handle, ptr(qkv), ptr(out), windows, tokens, heads))
+            ctx.synchronize()
+            outs.append(out.clone())
+        assert bool(torch.isfinite(outs[0].float()).all()), tokens
+        assert torch.equal(outs[1], outs[2]), tokens                       # two and three waves per SIMD: the same code
+        if not planted:
+            assert torch.equal(outs[0], outs[1]), tokens
+        else:
+            xx = qkv.double().reshape(windows, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+            ref = (torch.softmax((xx[0] @ xx[1].transpose(3, 2)) * math.log(2.0), dim=3) @ xx[2]).transpose(1, 2).reshape(windows * tokens, C)
+            for o_ in outs[:2]:
+                assert max_err_over_max(o_[:-1].float(), ref) < 2 * OUT_EPS[dtype], tokens
+                assert rel_l2(o_[:-1].float(), ref) < 1.5 * OUT_EPS[dtype], tokens
+            assert rel_l2(outs[1][:-1].float(), outs[0][:-1].float()) < OUT_EPS[dtype], tokens
+    for k in ("ME_ATT_V", "ME_ATT_MINW"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention3_recut_kernel(dtype, monkeypatch):
     """Round 5's re-cut of the forward pass's attention (csrc/attention3.hip, ME_ATT_V=3: 48 queries per wave on 16x16x32 MFMAs,
     persistent workgroups over 192-query items, the query beyond whole wave units on the vector pipe).  It lost its A/B in the

@@ -21,10 +21,12 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 VARIANTS = [
     ("v1 (round 1 kernel)", {}, False),
-    ("v2 4 waves x 32 q (round 4, the product)", {}, True),
-    ("v3 4 waves x 48 q, persistent (ME_ATT_V=3)", {"ME_ATT_V": "3"}, True),
+    ("v2 4 waves x 32 q (round 4)", {}, True),
+    ("v2p next tile's S ahead, 3 waves/SIMD", {"ME_ATT_V": "4"}, True),
+    ("v2p next tile's S ahead, 2 waves/SIMD", {"ME_ATT_V": "4", "ME_ATT_MINW": "2"}, True),
+    ("v3 4 waves x 48 q, persistent", {"ME_ATT_V": "3"}, True),
 ]
-KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES")
+KEYS = ("ME_ATT_V", "ME_ATT_THR", "ME_ATT_HALVES", "ME_ATT_MINW")
 
 
 def run(env, pre):
@@ -43,8 +45,9 @@ for name, env, pre in VARIANTS:
     torch.cuda.synchronize()
     outs[name] = out.float().clone()
 ref = outs[VARIANTS[0][0]]
+print("v2p == v2 bit for bit:", bool(torch.equal(outs[VARIANTS[1][0]], outs[VARIANTS[2][0]])), bool(torch.equal(outs[VARIANTS[1][0]], outs[VARIANTS[3][0]])))
 for name, o in outs.items():
-    print(f"{name:30s} finite {bool(torch.isfinite(o).all())}  rel-L2 vs v1 {float((o - ref).norm() / ref.norm()):.2e}", flush=True)
+    print(f"{name:42s} finite {bool(torch.isfinite(o).all())}  rel-L2 vs v1 {float((o - ref).norm() / ref.norm()):.2e}", flush=True)
 
 times = {name: [] for name, _, _ in VARIANTS}
 for r in range(ROUNDS):
@@ -59,4 +62,4 @@ for r in range(ROUNDS):
 flop = 4.0 * W * 16 * 577 * 577 * 64
 for name, ts in times.items():
     med = statistics.median(ts)
-    print(f"{name:30s} median {med:7.1f} us  min {min(ts):7.1f} us  {flop / med / 1e6:6.0f} TFLOP/s", flush=True)
+    print(f"{name:42s} median {med:7.1f} us  min {min(ts):7.1f} us  {flop / med / 1e6:6.0f} TFLOP/s", flush=True)
