@@ -167,7 +167,9 @@ enum EpiKind : int32_t {
     EPI_RESID_SCALE = 1, // out32[m][n] = res32[m][n] + gamma[n]*(acc + bias[n])  (ViT proj / fc2)
     EPI_PATCH_EMBED = 2, // out32[(m/P)*(P+1) + 1 + m%P][n] = acc + bias[n] + pos[1 + m%P][n]
     EPI_CONVT = 4,       // ConvTranspose2d(2,2,s2) pixel shuffle: n = (dy*2+dx)*Cout + co
-    EPI_HEAD_FINAL = 5   // relu(acc+bias) . w2 + b2 -> relu -> / f_norm -> clamp  (N <= 32)
+    EPI_HEAD_FINAL = 5,  // relu(acc+bias) . w2 + b2 -> relu -> / f_norm -> clamp  (N <= 32)
+    EPI_HEAD_COMPOSED = 6 // the same behind the composed ConvTranspose o conv3x3 of the head (weights.hip compose_head): N = 4
+                          // output phases x 32 channels on the half-resolution map, out32 = the full-resolution depth
 };
 
 enum Act : int32_t { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
@@ -205,6 +207,7 @@ struct GemmParams {
     int32_t tokens_per_window;  // EPI_PATCH_EMBED: P
     int32_t Cout;          // EPI_CONVT: N = 4*Cout
     // EPI_HEAD_FINAL
+    const float* head_tap_bias;  // EPI_HEAD_COMPOSED: f32 [9][32], the share of each 3x3 tap in `bias` (taken out at the image border)
     const float* w2;       // [N]
     const float* b2;       // device scalar
     const float* f_norm;   // device [B] (one per image) or null (= 1): out32[m] = clamp(v / f_norm[b])
@@ -286,6 +289,12 @@ void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, h
 // The depth head's final 3x3 (128 -> 32) + 1x1 (32 -> 1) on a pixel halo tile with the weights held in registers
 // (head_conv.hip); gemm_launch takes it for EPI_HEAD_FINAL where the shape fits (ME_HEAD_HALO=0: the implicit-GEMM tile)
 bool head_final_halo_fits(const GemmParams& p);
+// the head's ConvTranspose + conv3x3 + ReLU + conv1x1 + ReLU + / f_norm + clamp as ONE launch on the half-resolution map
+// (gemm_*_conv.hip: the 128-channel halo tile with the EPI_HEAD_COMPOSED epilogue).  p: A = bordered [B][H+2][W+2][Cin] 16-bit,
+// W = composed [128][9][Cin], bias = f32 [32], head_tap_bias = f32 [9][32], w2 / b2 / f_norm / clamp / pixels_per_image (of the
+// FULL-resolution map) as for EPI_HEAD_FINAL, out32 = depth [B][2H][2W]
+void head_composed_launch(const GemmParams& p, int32_t dtype, hipStream_t stream);
+bool head_composed_fits(const GemmParams& p);
 // compute units `stream` may use: the bits of its CU mask (hipExtStreamGetCUMask), the device's count when the stream
 // has no mask or the runtime cannot say
 int stream_cu_count(hipStream_t stream);

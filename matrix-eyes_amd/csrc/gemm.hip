@@ -181,6 +181,35 @@ int stream_cu_count(hipStream_t stream) {
     return granted;
 }
 
+void head_composed_launch_f16(const GemmParams& p, hipStream_t stream);
+void head_composed_launch_bf16(const GemmParams& p, hipStream_t stream);
+
+bool head_composed_fits(const GemmParams& p) {
+    return p.N == 128 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.Cin % 64 == 0 && p.K == 9 * p.Cin && p.out_H % 16 == 0 &&
+           p.out_W % 16 == 0 && p.M % 256 == 0 && p.M == (p.M / (p.out_H * p.out_W)) * p.out_H * p.out_W;
+}
+
+void head_composed_launch(const GemmParams& p_in, int32_t dtype, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.resident_out = nullptr, p.queue = nullptr, p.status = current_status_word();
+    p.cu_granted = stream_cu_count(stream);
+    ME_CHECK(head_composed_fits(p), ME_ERR_BAD_SHAPE, "composed head: %dx%d map, Cin %d, N %d", p.out_H, p.out_W, p.Cin, p.N);
+    ME_CHECK(p.A && p.W && p.bias && p.head_tap_bias && p.w2 && p.b2 && p.out32 && p.pixels_per_image == 4 * p.out_H * p.out_W,
+             ME_ERR_BAD_ARG, "composed head: missing operand");
+    static const bool log_launches = getenv("ME_LOG_LAUNCH") != nullptr;
+    if (log_launches) fprintf(stderr, "gemm_launch conv head_composed M=%d N=%d K=%d\n", p.M, p.N, p.K);
+    // algorithmic FLOPs: every output phase reads a 2 x 2 window of the 3 x 3 one (4 of 9 taps carry weights): the dense launch
+    // executes 9 / 4 of them; counted here are the FLOPs of the two layers it replaces at their own shapes (SURVEY App. B:
+    // ConvTranspose 2 * H * W * Cin * Cin * 4 + conv3x3 2 * 4 H W * Cin * 32 * 9)
+    const double px = (double)p.M;
+    ProfScope prof(stream, std::string("gemm_kernel<") + (dtype == ME_DTYPE_F16 ? "f16" : "bf16") + ",16x16px-x128x64/8w-halo,conv,head_composed>",
+                   2.0 * px * p.Cin * p.Cin * 4 + 2.0 * 4 * px * p.Cin * 32 * 9,
+                   px * p.Cin * 2 + (double)p.N * p.K * 2 + 4 * px * 4);
+    if (dtype == ME_DTYPE_F16) head_composed_launch_f16(p, stream);
+    else if (dtype == ME_DTYPE_BF16) head_composed_launch_bf16(p, stream);
+    else fail(ME_ERR_BAD_ARG, "composed head: bad dtype %d", dtype);
+}
+
 int gemm_lnf_resident(int32_t dtype, hipStream_t stream) {
     GemmParams p = GemmParams();
     int32_t resident = 0;

@@ -540,7 +540,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     asm volatile("" : "+v"(lane));
     const int frow = lane & 15;
     const int ncol = (lane >> 4) * 4;  // first of this lane's 4 consecutive n within a 16-tile
-    if constexpr (EPI == EPI_HEAD_FINAL) {
+    if constexpr (EPI == EPI_HEAD_COMPOSED) {
+        // The head behind its composed ConvTranspose o conv3x3 (weights.hip compose_head): this wave's TN = 32 columns are the 32
+        // channels of ONE output phase (dy, dx) = its column quarter; row t of the 16 x 16 pixel tile is half-resolution pixel
+        // (y, x), whose phase pixel is (2y + dy, 2x + dx) of the full-resolution map.  relu(acc + bias) . w2, reduced over the
+        // 32 channels (8 in the lane, 24 in three more lanes), + b2, ReLU, / f_norm, clamp -- EPI_HEAD_FINAL's arithmetic.
+        // At the image border the taps of the ORIGINAL 3x3 convolution that fall into its zero padding take their share of the
+        // bias with them (head_tap_bias; the activation part vanishes by itself, the operand being zero-bordered).
+        static_assert(TILE2D && TN == 32 && NI == 2, "the composed head runs on the 128-channel halo tile");
+        after_loads();
+        const int phase = (n0 + wn * TN) >> 5, dy = phase >> 1, dx = phase & 1;
+        float w2v[NI][4], bv[NI][4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = j * 16 + ncol + r;
+                w2v[j][r] = p.w2[ch];
+                bv[j][r] = p.bias[ch];
+            }
+        const int tx = p.out_W >> 4, ty = p.out_H / TILE_H;
+        const int img = m0 / (tx * ty);
+        const int rem = m0 - img * (tx * ty);
+        const int y0 = (rem / tx) * TILE_H, x0 = (rem - (rem / tx) * tx) * 16;
+        const int H2 = 2 * p.out_H, W2 = 2 * p.out_W;
+        const float fn = p.f_norm ? p.f_norm[img] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int t = wm * TM + i * 16 + frow;
+            const int Y = 2 * (y0 + (t >> 4)) + dy, X = 2 * (x0 + (t & 15)) + dx;
+            float b[NI][4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[j][r] = bv[j][r];
+            if (Y == 0 || Y == H2 - 1 || X == 0 || X == W2 - 1) {  // rare: one pixel in 384
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool out = (ky == 0 && Y == 0) || (ky == 2 && Y == H2 - 1) || (kx == 0 && X == 0) || (kx == 2 && X == W2 - 1);
+                        if (!out) continue;
+                        const float* tb = p.head_tap_bias + (ky * 3 + kx) * 32;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) b[j][r] -= tb[j * 16 + ncol + r];
+                    }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += fmaxf(acc[i][j][r] + b[j][r], 0.f) * w2v[j][r];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) {
+                float v = fmaxf(s + p.b2[0], 0.f);
+                if (p.f_norm) v = v / fn;
+                v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
+                p.out32[((int64_t)img * H2 + Y) * W2 + X] = v;
+            }
+        }
+    } else if constexpr (EPI == EPI_HEAD_FINAL) {
         // N <= 32 = the whole tile width (WN == 1): relu(acc + bias) . w2, reduced over n.
         after_loads();
         float w2v[NI][4], bv[NI][4];

@@ -6,4 +6,6 @@ template <>
 void gemm_dispatch<f16, A_CONV, EPI_HEAD_FINAL>(const GemmParams& p, int, hipStream_t stream) {
     gemm_launch_cfg<f16, 256, 32, 4, 1, A_CONV, EPI_HEAD_FINAL>(p, stream);
 }
+// the composed head (weights.hip compose_head) on the 128-channel halo tile
+void head_composed_launch_f16(const GemmParams& p, hipStream_t stream) { conv_halo_launch<f16, EPI_HEAD_COMPOSED, 16, 128>(p, stream); }
 }  // namespace me

@@ -77,6 +77,12 @@ struct ModelW {
     const void* dec_convs[5];  // [i] for level i (null for level 0)
     FusionW fusions[5];
     const void *head0_w, *head1_w, *head2_w;
+    // derived (weights.hip compose_head): head.1 (ConvTranspose 2x2 s2) and head.2 (conv 3x3) as ONE 3x3 convolution on the
+    // half-resolution map with 4 x 32 output channels (output phase (dy, dx) x channel), [128][9][Cmid] 16-bit; head_fused_b:
+    // f32 [32] bias of interior pixels, then [9][32] the share of each 3x3 tap in it (taken out again where the tap falls
+    // outside the full-resolution image).  Null when the composition does not apply (SPLIT_HEAD).
+    const void* head_fused_w = nullptr;
+    const float* head_fused_b = nullptr;
     const float *head0_b, *head1_b, *head2_b, *head4_w, *head4_b;
     const void *fov_lin_w, *fov_down_w, *fov_h0_w, *fov_h2_w;
     const float *fov_lin_b, *fov_down_b, *fov_h0_b, *fov_h2_b, *fov_h4_w, *fov_h4_b;
@@ -145,6 +151,7 @@ struct me_ctx {
     // derived weights (composed deconv + out_conv per fusion level): arena offsets, and the host copies of their
     // two factors kept from me_load_weight until me_weights_finalize composes them
     size_t fused_off[5] = {0, 0, 0, 0, 0};
+    size_t head_fused_off = 0;   // 0: not composed
     std::map<std::string, std::vector<float>> factor_keep;
 
     // me_status_flags: one device word the kernels OR bits into (ME_STATUS_OVERFLOW_16BIT: an f16 operand store
@@ -249,6 +256,7 @@ struct me_ctx {
         mix((uint64_t)dtype), mix(fp8 ? 1 : 0), mix((uint64_t)split_mask), mix(arena_bytes);
         for (const me::WeightSlot& s : slots) mix(s.offset), mix(s.bytes), mix((uint64_t)s.kind), mix(s.dup ? 1 : 0);
         for (int i = 0; i < 5; ++i) mix(fused_off[i]);
+        mix(head_fused_off);
         return h;
     }
 

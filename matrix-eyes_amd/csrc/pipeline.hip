@@ -854,6 +854,28 @@ void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* 
     const bool sp = ctx->split(SPLIT_HEAD);
     const size_t wide = sp ? 2 : 1;
     const void* f16b = ctx->bufs.at("features.16b").p;
+    // mod.rs:326-333 behind head[0]: ConvTranspose -> conv3x3 -> ReLU -> conv1x1 -> ReLU as ONE launch on the half-resolution map,
+    // the two linear layers composed at load time (weights.hip compose_head): the [B, 128, 1536, 1536] tensor between them (605 MB
+    // written and read back) never exists.  Needs the un-split chain and the 128-channel halo tile's shapes; ME_HEAD_COMPOSED=0:
+    // the three launches below.
+    static const bool composed_on = !(getenv("ME_HEAD_COMPOSED") && atoi(getenv("ME_HEAD_COMPOSED")) == 0);
+    if (composed_on && !sp && ctx->w.head_fused_w && Hh % 16 == 0 && (dec / 2) % 64 == 0 &&
+        ((int64_t)B * Hh * Hh) % 256 == 0) {
+        void* h0b = site_buf(ctx, "head.h0b", bordered_bytes(B, Hh, Hh, dec / 2));
+        ConvOut o;
+        o.out16 = h0b, o.border16 = true;
+        conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s, false);
+        GemmParams p = base_params();
+        p.M = B * Hh * Hh, p.N = 128, p.K = 9 * (dec / 2);
+        p.A = h0b, p.in_Hp = Hh + 2, p.in_Wp = Hh + 2, p.Cin = dec / 2, p.out_H = Hh, p.out_W = Hh;
+        p.KH = 3, p.KW = 3, p.stride = 1, p.W = ctx->w.head_fused_w, p.bias = ctx->w.head_fused_b;
+        p.head_tap_bias = ctx->w.head_fused_b + 32;
+        p.w2 = ctx->w.head4_w, p.b2 = ctx->w.head4_b, p.f_norm = f_norm_dev;
+        p.pixels_per_image = S * S, p.out32 = depth_dev;
+        p.clamp_lo = clamp ? 1e-4f : -INFINITY, p.clamp_hi = clamp ? 1e4f : INFINITY;
+        head_composed_launch(p, ctx->dtype, s);
+        return;
+    }
     void* h0 = site_buf(ctx, "head.h0", (size_t)B * Hh * Hh * (dec / 2) * 2 * wide);
     ConvOut o;
     o.out16 = h0, o.split16 = sp;

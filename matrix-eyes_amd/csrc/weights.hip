@@ -238,6 +238,12 @@ void build_weight_table(me_ctx* ctx) {
             ctx->fused_off[i] = ctx->arena_bytes;
             ctx->arena_bytes = align_up(ctx->arena_bytes + (size_t)(4 * dec) * (3 * dec) * 2, 256);
         }
+    // derived: head.1 o head.2 as one 3x3 convolution with 4 x 32 output channels (compose_head), + its f32 bias tables
+    ctx->head_fused_off = 0;
+    if (!ctx->split(SPLIT_HEAD)) {
+        ctx->head_fused_off = ctx->arena_bytes;
+        ctx->arena_bytes = align_up(ctx->arena_bytes + (size_t)128 * 9 * (dec / 2) * 2 + (size_t)(32 + 9 * 32) * 4, 256);
+    }
 }
 
 void resolve_weights(me_ctx* ctx) {
@@ -278,6 +284,8 @@ void resolve_weights(me_ctx* ctx) {
     w.head1_w = vptr(ctx, "head.1.weight"), w.head1_b = fptr(ctx, "head.1.bias");
     w.head2_w = vptr(ctx, "head.2.weight"), w.head2_b = fptr(ctx, "head.2.bias");
     w.head4_w = fptr(ctx, "head.4.weight"), w.head4_b = fptr(ctx, "head.4.bias");
+    w.head_fused_w = ctx->head_fused_off ? (const void*)(ctx->arena + ctx->head_fused_off) : nullptr;
+    w.head_fused_b = ctx->head_fused_off ? (const float*)(ctx->arena + ctx->head_fused_off + (size_t)128 * 9 * (c.dec_dim / 2) * 2) : nullptr;
     w.fov_lin_w = vptr(ctx, "fov.encoder.1.weight"), w.fov_lin_b = fptr(ctx, "fov.encoder.1.bias");
     w.fov_down_w = vptr(ctx, "fov.downsample.0.weight");
     w.fov_down_b = fptr(ctx, "fov.downsample.0.bias");
@@ -315,6 +323,11 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
     if (ctx->split(SPLIT_FUSION_OUT) && s.name.rfind("decoder.fusions.", 0) == 0 &&
         (s.name.find(".deconv.weight") != std::string::npos || s.name.find(".out_conv.weight") != std::string::npos)) {
         std::vector<float>& keep = ctx->factor_keep[s.name];  // composed at finalize (compose_fusion_out)
+        keep.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) keep[i] = src.get(i);
+    }
+    if (ctx->head_fused_off && (s.name == "head.1.weight" || s.name == "head.1.bias" || s.name == "head.2.weight" || s.name == "head.2.bias")) {
+        std::vector<float>& keep = ctx->factor_keep[s.name];  // composed at finalize (compose_head)
         keep.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) keep[i] = src.get(i);
     }
@@ -484,6 +497,105 @@ static void compose_fusion_out(me_ctx* ctx) {
     // the factors stay (2 MB of host memory): a later me_load_weight of one of them recomposes at the next finalize
 }
 
+// mod.rs:73-94,326-333: head[1] = ConvTranspose2d(128 -> 128, 2 x 2, stride 2, bias) and head[2] = Conv2d(128 -> 32, 3 x 3, padding 1,
+// bias) have nothing between them, so they are ONE linear map from the half-resolution map X to the full-resolution one.  An
+// output pixel (2y + dy, 2x + dx) reads the ConvTranspose output U at rows 2y + dy + ky - 1 = 2 (y + iy) + ry, i.e. input rows
+// y + iy with iy in {-1, 0, 1} -- each output PHASE (dy, dx) is a convolution of X over a 2 x 2 window inside the 3 x 3 one:
+//   V[2y + dy][2x + dx][co] = b'[co] + sum_{iy, ix, ci} X[y + iy][x + ix][ci] * W'[(dy, dx), co][iy + 1][ix + 1][ci],
+//   W'[(dy, dx), co][iy + 1][ix + 1][ci] = sum over the (ky, kx) that land on (iy, ry), (ix, rx) of
+//                                          sum_c Wt[ci][c][ry][rx] * W3[co][c][ky][kx],
+// a 3 x 3 convolution with 4 x 32 output channels on the 768 x 768 map (the halo tile with 128 channels) -- the 605 MB
+// [1, 128, 1536, 1536] tensor of mod.rs:328 is never written or read (SURVEY 7 "hard part"), and the
+// ConvTranspose's launch and FLOPs go.  Bias: b'[co] = b3[co] + sum_{ky, kx} Cb[ky][kx][co], Cb = sum_c bT[c] W3[co][c][ky][kx];
+// where tap (ky, kx) of the 3 x 3 convolution falls outside the full-resolution image (its zero padding) the epilogue takes
+// that tap's share out again (X is zero-bordered, so the X part vanishes by itself).  Composed in f64 from the checkpoint's
+// values, rounded once to the operand type; rows of output channels beyond head_dims[0] are zero.
+static void compose_head(me_ctx* ctx) {
+    if (!ctx->head_fused_off) return;
+    const int64_t Cm = ctx->cfg.dec_dim / 2, Co = ctx->cfg.head_dims[0];
+    const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
+    auto to16 = [&](float f) { return to_bf16 ? float_to_bf16(f) : float_to_half(f); };
+    const char* names[4] = {"head.1.weight", "head.1.bias", "head.2.weight", "head.2.bias"};
+    bool any = false;
+    for (const char* nm : names) any = any || ctx->factor_keep.count(nm);
+    if (!any) return;  // nothing (re)loaded on this context: the arena's own composition (me_weights_adopt / broadcast)
+    for (const char* nm : names)
+        if (!ctx->slots[ctx->slot_by_name.at(nm)].loaded) return;  // finalize reports the missing one
+    auto from16 = [&](uint16_t h) {
+        if (!to_bf16) return half_to_float(h);
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    // a factor without a host copy (the arena was adopted, then some head tensor reloaded): back from its packed slot
+    auto fetch = [&](const std::string& name) -> const std::vector<float>& {
+        auto it = ctx->factor_keep.find(name);
+        if (it != ctx->factor_keep.end()) return it->second;
+        const WeightSlot& s = ctx->slots[ctx->slot_by_name.at(name)];
+        std::vector<float> out((size_t)s.numel());
+        if (s.kind == PK_VEC_F32) {
+            ME_HIP(hipMemcpy(out.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint16_t> raw(s.bytes / 2);
+            ME_HIP(hipMemcpy(raw.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
+            const int64_t Dd = s.dup ? 2 : 1;
+            if (s.kind == PK_CONVT_16) {  // [(q*Cout + co)][Dd * Cin] -> [Cin][Cout][q]
+                const int64_t Cin = s.dims[0], Cout = s.dims[1];
+                for (int64_t ci = 0; ci < Cin; ++ci)
+                    for (int64_t co = 0; co < Cout; ++co)
+                        for (int64_t q = 0; q < 4; ++q) out[(ci * Cout + co) * 4 + q] = from16(raw[(q * Cout + co) * Dd * Cin + ci]);
+            } else {  // PK_CONV_16 [Cout][kk][Dd * Cin] -> [Cout][Cin][kk]
+                const int64_t Cout = s.dims[0], Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
+                for (int64_t co = 0; co < Cout; ++co)
+                    for (int64_t ci = 0; ci < Cin; ++ci)
+                        for (int64_t t = 0; t < kk; ++t) out[(co * Cin + ci) * kk + t] = from16(raw[(co * kk + t) * Dd * Cin + ci]);
+            }
+        }
+        return ctx->factor_keep.emplace(name, std::move(out)).first->second;
+    };
+    const std::vector<float>& Wt = fetch("head.1.weight");  // [ci][c][dy][dx]
+    const std::vector<float>& bT = fetch("head.1.bias");    // [c]
+    const std::vector<float>& W3 = fetch("head.2.weight");  // [co][c][ky][kx]
+    const std::vector<float>& b3 = fetch("head.2.bias");    // [co]
+    std::vector<double> Wp((size_t)128 * 9 * Cm, 0.0);      // [(phase * 32 + co)][tap][ci]
+    std::vector<double> w3row((size_t)Cm);
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ay = dy + ky - 1, ax = dx + kx - 1;
+                    const int iy = ay < 0 ? -1 : ay / 2, ix = ax < 0 ? -1 : ax / 2;  // floor(a / 2) for a in -1 .. 2
+                    const int ry = ay - 2 * iy, rx = ax - 2 * ix;
+                    const int tap = (iy + 1) * 3 + (ix + 1), q = ry * 2 + rx;
+                    for (int64_t co = 0; co < Co; ++co) {
+                        for (int64_t c = 0; c < Cm; ++c) w3row[c] = (double)W3[((co * Cm + c) * 3 + ky) * 3 + kx];
+                        double* dst = &Wp[(((size_t)(dy * 2 + dx) * 32 + co) * 9 + tap) * Cm];
+                        for (int64_t ci = 0; ci < Cm; ++ci) {
+                            const float* wt = &Wt[(size_t)ci * Cm * 4 + q];  // Wt[ci][c][ry][rx], c strided by 4
+                            double a = 0.0;
+                            for (int64_t c = 0; c < Cm; ++c) a += (double)wt[c * 4] * w3row[c];
+                            dst[ci] += a;
+                        }
+                    }
+                }
+    std::vector<uint16_t> packed((size_t)128 * 9 * Cm);
+    for (size_t i = 0; i < packed.size(); ++i) packed[i] = to16((float)Wp[i]);
+    std::vector<float> tab((size_t)32 + 9 * 32, 0.f);  // [32] interior bias, [9][32] per-tap shares
+    for (int64_t co = 0; co < Co; ++co) {
+        double bsum = (double)b3[co];
+        for (int t = 0; t < 9; ++t) {
+            double a = 0.0;
+            for (int64_t c = 0; c < Cm; ++c) a += (double)bT[c] * (double)W3[(co * Cm + c) * 9 + t];
+            tab[32 + t * 32 + co] = (float)a;
+            bsum += a;
+        }
+        tab[co] = (float)bsum;
+    }
+    ME_HIP(hipMemcpy(ctx->arena + ctx->head_fused_off, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    ME_HIP(hipMemcpy(ctx->arena + ctx->head_fused_off + packed.size() * 2, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+}
+
 // ME_DTYPE_FP8: quantise qkv / proj / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
 // to MX fp8 on the device.  Derived data: a rank that received the arena by broadcast rebuilds it itself.
 void build_fp8_weights(me_ctx* ctx) {
@@ -534,6 +646,7 @@ void finalize_weights(me_ctx* ctx) {
     ME_CHECK(n == 0, ME_ERR_MISSING_WEIGHT, "%d tensors missing from the checkpoint: %s%s", n,
              missing.c_str(), n > 8 ? ", ..." : "");
     compose_fusion_out(ctx);
+    compose_head(ctx);
     build_fp8_weights(ctx);
     ctx->finalized = true;
     ctx->drop_graph(), ++ctx->weights_generation;

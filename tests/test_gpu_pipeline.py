@@ -609,6 +609,57 @@ def test_tile_choices_change_no_bit(tmp_path):
     assert np.isfinite(outs[3]).all() and 0 < fused_err < 1.5e-3
 
 
+_HEAD_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import matrix_eyes_amd as m
+from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+cfg = m.ModelConfig.tiny()
+w = dict(synthetic_checkpoint(cfg))
+# a ConvTranspose bias large enough that a wrong border term would show: the composed form takes the share of every 3x3 tap
+# that falls into the zero padding of the full-resolution map out of its bias
+import torch
+w["head.1.bias"] = torch.as_tensor(w["head.1.bias"]).float() * 0 + torch.linspace(-0.5, 0.5, cfg.dec_dim // 2)
+ctx = m.Context(0, "f16", cfg)
+ctx.load_state_dict(w)
+rgb = synthetic_images(2, cfg.img_size, "structured", seed=5)
+d = ctx.extract_depth(rgb, 1.0)
+canon = ctx.extract_depth(rgb, 1.0)       # repeatable
+assert np.array_equal(d, canon)
+np.save(sys.argv[2], d)
+"""
+
+
+def test_composed_head_equals_the_three_layers(tmp_path):
+    """VERDICT r4 item 4b.  head[1] (ConvTranspose 128 -> 128) and head[2] (conv3x3 128 -> 32) composed at load time into one
+    3x3 convolution with 4 phases x 32 channels on the half-resolution map (weights.hip compose_head, EPI_HEAD_COMPOSED) against
+    the three launches it replaces (ME_HEAD_COMPOSED=0), tiny model, a batch of two, with a deliberately large ConvTranspose
+    bias: the maps agree to the 16-bit rounding the composed form SKIPS (the ConvTranspose output is no longer rounded to an
+    operand), on the one-pixel frame -- where taps of the 3x3 convolution fall into its zero padding and the composed bias
+    changes -- as well as inside, and both sit at the same distance from the fp32 oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("composed", {}), ("layers", {"ME_HEAD_COMPOSED": "0"})):
+        path = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _HEAD_CHILD, root, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path)
+    a, b = outs["composed"], outs["layers"]
+    assert np.isfinite(a).all() and a.shape == b.shape and not np.array_equal(a, b)
+    assert rel_l2(a, b) < 6e-4
+    frame = np.ones(a.shape[1:], bool)
+    frame[1:-1, 1:-1] = False
+    scale = np.sqrt((b ** 2).mean())
+    inner_err = np.abs(a - b)[:, ~frame].max() / scale
+    frame_err = np.abs(a - b)[:, frame].max() / scale
+    print("composed head vs three layers: rel-L2", rel_l2(a, b), "max |d| / rms inside", inner_err, "on the frame", frame_err)
+    assert frame_err < 3 * inner_err + 1e-3      # a missing border term would be of the order of the bias: 10 - 100 x this
+
+
 _LN_FALLBACK_CHILD = """
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
