@@ -34,7 +34,7 @@ VIT_WINDOW_GFLOP = 382.13
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_PEAK_TFLOPS_FP8 = 5000.0  # dense MX-scaled fp8, MI355X_MICROARCH.md "Peak FP8 MFMA"
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_kernels.json")
 # Box calibration.  ctx.calibrate() runs two FIXED loops of the library (csrc/calibrate.hip, never
 # to be edited): an MFMA-only loop and a 512 MiB device copy.  The reference below is the first box measured in round 5
 # (profiles/r05_calibration_boxes.json lists every box that produced a profiles/r05_* file); `value_normalised` is what
@@ -75,7 +75,7 @@ def pmc_traffic(kernel_name):
             return None, None, None, "no PMC pass for this kernel"
         n = float(len(ops))
         return (sum(v["hbm_bytes"] for v in ops) / n, sum(v["algorithmic_bytes"] for v in ops) / n,
-                sum(v["mfma_util"] for v in ops) / n, f"profiles/r04_pmc_kernels.json, source sha {meta['source_sha']}")
+                sum(v["mfma_util"] for v in ops) / n, f"profiles/r05_pmc_kernels.json, source sha {meta['source_sha']}")
     except Exception as e:   # no file: traffic stays null
         return None, None, None, f"no PMC file ({type(e).__name__})"
 

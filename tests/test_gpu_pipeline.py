@@ -636,7 +636,7 @@ def test_composed_head_equals_the_three_layers(tmp_path):
     the three launches it replaces (ME_HEAD_COMPOSED=0), tiny model, a batch of two, with a deliberately large ConvTranspose
     bias: the maps agree to the 16-bit rounding the composed form SKIPS (the ConvTranspose output is no longer rounded to an
     operand), on the one-pixel frame -- where taps of the 3x3 convolution fall into its zero padding and the composed bias
-    changes -- as well as inside, and both sit at the same distance from the fp32 oracle."""
+    changes -- as well as inside.  (test_extract_depth_tiny / the full-size pairs hold the composed form to the fp32 oracle.)"""
     import os
     import subprocess
     import sys
