@@ -717,7 +717,7 @@ void extract_depth_impl(me_ctx* ctx, const float* img_dev, int32_t batch, const 
     OutBuf o = out_buf(ctx, inverse_depth, (size_t)batch * S * S * 4, "io.depth");
     {
         ProgressRange r(ctx, head_lo, 1.0f);
-        stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev);
+        stage_head(ctx, batch, fnorm_dev, true, (float*)o.dev, ctx->features_pre);
     }
     finish(ctx, o);
     if (!f_norm && fov_deg_out) finish(ctx, ofov);

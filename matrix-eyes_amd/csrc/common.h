@@ -207,7 +207,10 @@ struct GemmParams {
     int32_t tokens_per_window;  // EPI_PATCH_EMBED: P
     int32_t Cout;          // EPI_CONVT: N = 4*Cout
     // EPI_HEAD_FINAL
-    const float* head_tap_bias;  // EPI_HEAD_COMPOSED: f32 [9][32], the share of each 3x3 tap in `bias` (taken out at the image border)
+    // f32 [9][ld]: the share of each 3x3 tap in `bias`, taken out again where the tap falls into the zero padding of a layer that
+    // was composed into this convolution at load time (weights.hip compose_head: EPI_HEAD_COMPOSED, ld = 32; compose_features: the
+    // halo tile's EPI_STORE with a bordered 16-bit output, ld = N)
+    const float* tap_bias;
     const float* w2;       // [N]
     const float* b2;       // device scalar
     const float* f_norm;   // device [B] (one per image) or null (= 1): out32[m] = clamp(v / f_norm[b])
@@ -291,7 +294,7 @@ void gemm_launch(const GemmParams& p, AMode amode, EpiKind epi, int32_t dtype, h
 bool head_final_halo_fits(const GemmParams& p);
 // the head's ConvTranspose + conv3x3 + ReLU + conv1x1 + ReLU + / f_norm + clamp as ONE launch on the half-resolution map
 // (gemm_*_conv.hip: the 128-channel halo tile with the EPI_HEAD_COMPOSED epilogue).  p: A = bordered [B][H+2][W+2][Cin] 16-bit,
-// W = composed [128][9][Cin], bias = f32 [32], head_tap_bias = f32 [9][32], w2 / b2 / f_norm / clamp / pixels_per_image (of the
+// W = composed [128][9][Cin], bias = f32 [32], tap_bias = f32 [9][32], w2 / b2 / f_norm / clamp / pixels_per_image (of the
 // FULL-resolution map) as for EPI_HEAD_FINAL, out32 = depth [B][2H][2W]
 void head_composed_launch(const GemmParams& p, int32_t dtype, hipStream_t stream);
 bool head_composed_fits(const GemmParams& p);

@@ -194,7 +194,7 @@ void head_composed_launch(const GemmParams& p_in, int32_t dtype, hipStream_t str
     p.resident_out = nullptr, p.queue = nullptr, p.status = current_status_word();
     p.cu_granted = stream_cu_count(stream);
     ME_CHECK(head_composed_fits(p), ME_ERR_BAD_SHAPE, "composed head: %dx%d map, Cin %d, N %d", p.out_H, p.out_W, p.Cin, p.N);
-    ME_CHECK(p.A && p.W && p.bias && p.head_tap_bias && p.w2 && p.b2 && p.out32 && p.pixels_per_image == 4 * p.out_H * p.out_W,
+    ME_CHECK(p.A && p.W && p.bias && p.tap_bias && p.w2 && p.b2 && p.out32 && p.pixels_per_image == 4 * p.out_H * p.out_W,
              ME_ERR_BAD_ARG, "composed head: missing operand");
     static const bool log_launches = getenv("ME_LOG_LAUNCH") != nullptr;
     if (log_launches) fprintf(stderr, "gemm_launch conv head_composed M=%d N=%d K=%d\n", p.M, p.N, p.K);
@@ -262,6 +262,10 @@ void gemm_launch(const GemmParams& p_in, AMode amode, EpiKind epi, int32_t dtype
                  (long long)p.lda, p.K);
     }
     if (epi == EPI_HEAD_FINAL) ME_CHECK(p.N <= 32, ME_ERR_BAD_SHAPE, "head: N=%d > 32", p.N);
+    if (p.tap_bias)  // the epilogue needs the output pixel's coordinates: the bordered 16-bit output has them
+        ME_CHECK(amode == A_CONV && epi == EPI_STORE && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.out16 && p.out16_border && p.bias &&
+                     p.N % 8 == 0 && !p.out32 && !p.res32 && !p.res32b && !p.lo_off16 && !p.hi2_off16 && p.act != ACT_GELU,
+                 ME_ERR_BAD_ARG, "conv: per-tap bias shares take a 3x3 stride-1 convolution with a bordered 16-bit output and nothing else");
     if (p.ln_out16) {
         ME_CHECK(force_cfg == CFG_PP352 && amode == A_PLAIN && epi == EPI_RESID_SCALE && (p.N == 256 || p.N == 512 || p.N == 1024) &&
                      p.ldc == p.N && p.ln_w && p.ln_b && p.ln_stats && p.ln_count && p.bias && p.gamma && p.res32 && p.out32 &&

@@ -313,7 +313,8 @@ constexpr int epi_mi_chunk(int MI, int TN, int NW, int main_bytes) {
 #define ME_EPI_PRE 1
 #endif
 // epilogue_granule<EPI_STORE, MODE >= kEpiConst>: which options of the launch are compiled in
-constexpr int kEpiConst = 16, kEpiRes = 1, kEpiOut32 = 2, kEpiOut16 = 4, kEpiBorder = 8, kEpiLo = 32, kEpiHi2 = 64, kEpiResB = 128;
+constexpr int kEpiConst = 16, kEpiRes = 1, kEpiOut32 = 2, kEpiOut16 = 4, kEpiBorder = 8, kEpiLo = 32, kEpiHi2 = 64, kEpiResB = 128,
+              kEpiTapBias = 256;
 struct EpiLane {
     float4 bias[2], gamma[2];  // per-lane constants for columns n..n+3 and n+4..n+7
     int q, co;                 // EPI_CONVT: n = q * Cout + co
@@ -411,6 +412,15 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
         const bool f_border = CF ? (MODE & kEpiBorder) != 0 : p.out16_border != 0;
         const bool f_lo = CF ? (MODE & kEpiLo) != 0 : p.lo_off16 != 0;
         const bool f_hi2 = CF ? (MODE & kEpiHi2) != 0 : p.hi2_off16 != 0;
+        // GemmParams::tap_bias (a layer composed into this 3x3 convolution, weights.hip compose_features): at the image border the
+        // taps that fall into the zero padding take their share of the bias with them (r.y / r.x: the bordered output's pixel).
+        // A compiled-in mode only (gemm_launch admits tap_bias with exactly that mode's options): as a run-time option of MODE 0
+        // the plain-GEMM kernels that also carry this body stopped compiling (their LDS-DMA's wave-uniform operands came out in
+        // VGPRs).  A wave-uniform branch around branch-free arithmetic.
+        const bool f_tap = CF ? (MODE & kEpiTapBias) != 0 : false;
+        // (a wave-uniform branch around branch-free arithmetic: a divergent one here let the optimiser thread the kernels' tile
+        // loops through it, and the LDS-DMA's wave-uniform operands came out in VGPRs)
+        const bool at_edge = f_tap && __builtin_amdgcn_ballot_w64(r.y == 0 || r.y == p.out_H - 1 || r.x == 0 || r.x == p.out_W - 1) != 0;
         // CF: ReLU (or none) as max(x, bound): bound16 for the 16-bit copy, bound32 for the f32 output (act16_only: unclamped)
         const float bound16 = p.act == ACT_RELU ? 0.f : -INFINITY;
         const float bound32 = (p.act == ACT_RELU && !p.act16_only) ? 0.f : -INFINITY;
@@ -420,6 +430,16 @@ __device__ __forceinline__ void epilogue_granule(const GemmParams& p, const EpiR
             if (h == 1 && !hi_ok) break;
             float x0 = v[h][0] + lc.bias[h].x, x1 = v[h][1] + lc.bias[h].y;
             float x2 = v[h][2] + lc.bias[h].z, x3 = v[h][3] + lc.bias[h].w;
+            if (at_edge) {  // rare: the tiles along the image border
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t % 3;
+                    const bool out = (ky == 0 && r.y == 0) || (ky == 2 && r.y == p.out_H - 1) || (kx == 0 && r.x == 0) ||
+                                     (kx == 2 && r.x == p.out_W - 1);
+                    const float4 t4 = *reinterpret_cast<const float4*>(p.tap_bias + t * p.N + n + 4 * h);
+                    x0 -= out ? t4.x : 0.f, x1 -= out ? t4.y : 0.f, x2 -= out ? t4.z : 0.f, x3 -= out ? t4.w : 0.f;
+                }
+            }
             if (f_res) {
                 const float4 r4 = (CF && ME_EPI_PRE) ? pre[h] : *reinterpret_cast<const float4*>(p.res32 + row32 + n + 4 * h);
                 x0 += r4.x, x1 += r4.y, x2 += r4.z, x3 += r4.w;
@@ -546,7 +566,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         // (y, x), whose phase pixel is (2y + dy, 2x + dx) of the full-resolution map.  relu(acc + bias) . w2, reduced over the
         // 32 channels (8 in the lane, 24 in three more lanes), + b2, ReLU, / f_norm, clamp -- EPI_HEAD_FINAL's arithmetic.
         // At the image border the taps of the ORIGINAL 3x3 convolution that fall into its zero padding take their share of the
-        // bias with them (head_tap_bias; the activation part vanishes by itself, the operand being zero-bordered).
+        // bias with them (tap_bias; the activation part vanishes by itself, the operand being zero-bordered).
         static_assert(TILE2D && TN == 32 && NI == 2, "the composed head runs on the 128-channel halo tile");
         after_loads();
         const int phase = (n0 + wn * TN) >> 5, dy = phase >> 1, dx = phase & 1;
@@ -579,7 +599,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     for (int kx = 0; kx < 3; ++kx) {
                         const bool out = (ky == 0 && Y == 0) || (ky == 2 && Y == H2 - 1) || (kx == 0 && X == 0) || (kx == 2 && X == W2 - 1);
                         if (!out) continue;
-                        const float* tb = p.head_tap_bias + (ky * 3 + kx) * 32;
+                        const float* tb = p.tap_bias + (ky * 3 + kx) * 32;
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -948,7 +968,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                                 !p.lo_off16 && !p.ldc16;
             // the convolutions' combinations (no second residual, no GELU): compiled-in options
             const int mask = (p.res32 ? kEpiRes : 0) | (p.res32b ? kEpiResB : 0) | (p.out32 ? kEpiOut32 : 0) | (p.out16 ? kEpiOut16 : 0) |
-                             (p.out16_border ? kEpiBorder : 0) | (p.lo_off16 ? kEpiLo : 0) | (p.hi2_off16 ? kEpiHi2 : 0);
+                             (p.out16_border ? kEpiBorder : 0) | (p.lo_off16 ? kEpiLo : 0) | (p.hi2_off16 ? kEpiHi2 : 0) |
+                             (p.tap_bias ? kEpiTapBias : 0);
             // (not in the 352-row tile's kernel, MI == 11: it serves the ViT's qkv / fc1 through modes 1 and 2, and the other
             // bodies beside them cost it registers -- per-pass scratch reloads inside its store loops)
             constexpr bool CF_MODES = CF_ALLOWED && MI != 11;  // (CF_ALLOWED false: the fp8 GEMM, whose 16-bit stores are mode 1)
@@ -967,6 +988,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                         run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut32 | kEpiOut16 | kEpiBorder>());
                     else if (mask == (kEpiRes | kEpiResB | kEpiOut32 | kEpiOut16 | kEpiBorder))
                         run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiResB | kEpiOut32 | kEpiOut16 | kEpiBorder>());
+                    else if (mask == (kEpiOut16 | kEpiBorder | kEpiTapBias))
+                        run(std::integral_constant<int, kEpiConst | kEpiOut16 | kEpiBorder | kEpiTapBias>());
+                    else if (mask == (kEpiRes | kEpiOut16 | kEpiBorder))
+                        run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut16 | kEpiBorder>());
                     else if (mask == (kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2))
                         run(std::integral_constant<int, kEpiConst | kEpiRes | kEpiOut16 | kEpiLo | kEpiHi2>());
                     else if (mask == (kEpiRes | kEpiOut16 | kEpiLo))

@@ -83,6 +83,10 @@ struct ModelW {
     // outside the full-resolution image).  Null when the composition does not apply (SPLIT_HEAD).
     const void* head_fused_w = nullptr;
     const float* head_fused_b = nullptr;
+    // derived (weights.hip compose_features): fusions[0].out_conv and head.0 as ONE 3x3 convolution of out_conv's input,
+    // [dec / 2][9][dec] 16-bit; feat_fused_b: f32 [dec / 2] bias + [9][dec / 2] per-tap shares
+    const void* feat_fused_w = nullptr;
+    const float* feat_fused_b = nullptr;
     const float *head0_b, *head1_b, *head2_b, *head4_w, *head4_b;
     const void *fov_lin_w, *fov_down_w, *fov_h0_w, *fov_h2_w;
     const float *fov_lin_b, *fov_down_b, *fov_h0_b, *fov_h2_b, *fov_h4_w, *fov_h4_b;
@@ -152,6 +156,8 @@ struct me_ctx {
     // two factors kept from me_load_weight until me_weights_finalize composes them
     size_t fused_off[5] = {0, 0, 0, 0, 0};
     size_t head_fused_off = 0;   // 0: not composed
+    size_t feat_fused_off = 0;   // 0: not composed
+    bool features_pre = false;   // "features.16b" holds out_conv's INPUT (stage_decoder_levels with the composed head[0])
     std::map<std::string, std::vector<float>> factor_keep;
 
     // me_status_flags: one device word the kernels OR bits into (ME_STATUS_OVERFLOW_16BIT: an f16 operand store
@@ -257,6 +263,7 @@ struct me_ctx {
         for (const me::WeightSlot& s : slots) mix(s.offset), mix(s.bytes), mix((uint64_t)s.kind), mix(s.dup ? 1 : 0);
         for (int i = 0; i < 5; ++i) mix(fused_off[i]);
         mix(head_fused_off);
+        mix(feat_fused_off);
         return h;
     }
 
@@ -315,7 +322,7 @@ void stage_decoder_levels(me_ctx* ctx, int B, bool want_features32, int first, i
 void stage_fov_vit(me_ctx* ctx, int B, hipStream_t s);
 void stage_fov_tail(me_ctx* ctx, int B, float* fov_deg_dev);
 // f_norm_dev [B]; clamp 0 = canonical (no clamp, f_norm ignored -> 1)
-void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev);
+void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev, bool pre_image = false);
 
 void report(me_ctx* ctx, float pos, const char* msg);
 

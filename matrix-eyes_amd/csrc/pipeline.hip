@@ -98,6 +98,7 @@ struct ConvOut {
     bool act16_only = true;
     const float* res32 = nullptr;
     const float* res32b = nullptr;
+    const float* tap_bias = nullptr;  // GemmParams::tap_bias ([9][Cout]; needs border16)
 };
 
 // Conv2d k x k (k = 1 or 3, pad (k-1)/2, stride 1 or 2) on a zero-bordered NHWC operand
@@ -110,7 +111,7 @@ void conv(me_ctx* ctx, const void* in16b, int B, int Hin, int Win, int Cin, cons
     p.M = B * Ho * Wo, p.N = Cout, p.K = k * k * Cin;
     p.A = in16b, p.in_Hp = Hin + 2, p.in_Wp = Win + 2, p.Cin = Cin;
     p.out_H = Ho, p.out_W = Wo, p.KH = k, p.KW = k, p.stride = stride;
-    p.W = W, p.bias = bias, p.res32 = o.res32, p.res32b = o.res32b;
+    p.W = W, p.bias = bias, p.res32 = o.res32, p.res32b = o.res32b, p.tap_bias = o.tap_bias;
     p.out32 = o.out32, p.out16 = o.out16, p.ldc = Cout, p.out16_border = o.border16 ? 1 : 0;
     p.act = o.act, p.act16_only = o.act16_only ? 1 : 0;
     if (o.split16) set_out16_split(p, Cout);
@@ -738,6 +739,15 @@ void stage_encoder_trunk(me_ctx* ctx, const float* img32, int B, bool fov_async 
     }
 }
 
+// the head behind head[0] as one launch on the half-resolution map (stage_head): needs the un-split chain and the 128-channel
+// halo tile's shapes; ME_HEAD_COMPOSED=0: the three launches
+static bool head_composed_applies(const me_ctx* ctx, int B) {
+    static const bool composed_on = !(getenv("ME_HEAD_COMPOSED") && atoi(getenv("ME_HEAD_COMPOSED")) == 0);
+    const int dec = ctx->cfg.dec_dim, Hh = ctx->S() / 2;
+    return composed_on && !ctx->split(SPLIT_HEAD) && ctx->w.head_fused_w && Hh % 16 == 0 && (dec / 2) % 64 == 0 &&
+           ((int64_t)B * Hh * Hh) % 256 == 0;
+}
+
 // decoder.rs:153-208 MultiresConvDecoder::forward (+ :84-102 FeatureFusionBlock, :35-44 RCU)
 void stage_decoder(me_ctx* ctx, int B, bool want_features32) { stage_decoder_levels(ctx, B, want_features32, 4, 0); }
 
@@ -804,6 +814,20 @@ void stage_decoder_levels(me_ctx* ctx, int B, bool want_features32, int first, i
         // [hi | lo | hi] where the two are composed into one ConvTranspose (FusionW::fused_w)
         const bool fused = spf && fw.deconv && fw.fused_w;
         const size_t wf = fused ? 3 : (spf ? 2 : 1);
+        if (i == 0) {
+            // decoder.rs:101 out_conv + mod.rs:326 head[0] as ONE convolution (weights.hip compose_features): this level's last
+            // convolution writes out_conv's INPUT as head[0]'s zero-bordered operand, the 1x1 launch and the feature map between
+            // them (0.9 GB of traffic at 768 x 768) go.  Not when the caller wants the features themselves, nor under SPLIT_HEAD;
+            // ME_FEAT_COMPOSED=0: the two layers as they are.
+            static const bool feat_composed_on = !(getenv("ME_FEAT_COMPOSED") && atoi(getenv("ME_FEAT_COMPOSED")) == 0);
+            ctx->features_pre = feat_composed_on && !want_features32 && head_composed_applies(ctx, B) && ctx->w.feat_fused_w;
+            if (ctx->features_pre) {
+                ConvOut o4;
+                o4.out16 = site_buf(ctx, "features.16b", bordered_bytes(B, h, h, dec)), o4.border16 = true, o4.res32 = out32;
+                conv(ctx, t2_r16, B, h, h, dec, fw.resnet2.w[1], dec, 3, 1, fw.resnet2.b[1], o4, s);
+                continue;
+            }
+        }
         void* v16 = site_buf(ctx, L + ".v16", (size_t)B * h * h * dec * 2 * wf);
         ConvOut o4;
         o4.out16 = v16, o4.res32 = out32, o4.split16 = spf, o4.triple16 = fused;
@@ -845,7 +869,8 @@ void stage_decoder_levels(me_ctx* ctx, int B, bool want_features32, int first, i
 }
 
 // mod.rs:323-333 head convs + ReLUs, mod.rs:361-362 div_scalar + clamp fused into the last kernel
-void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev) {
+// pre_image: "features.16b" holds the input of the last fusion block's out_conv instead of its output (ctx->features_pre)
+void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* depth_dev, bool pre_image) {
     hipStream_t s = ctx->stream;
     const me_model_config& c = ctx->cfg;
     const int dec = c.dec_dim, S = ctx->S(), Hh = S / 2;
@@ -858,18 +883,22 @@ void stage_head(me_ctx* ctx, int B, const float* f_norm_dev, bool clamp, float* 
     // the two linear layers composed at load time (weights.hip compose_head): the [B, 128, 1536, 1536] tensor between them (605 MB
     // written and read back) never exists.  Needs the un-split chain and the 128-channel halo tile's shapes; ME_HEAD_COMPOSED=0:
     // the three launches below.
-    static const bool composed_on = !(getenv("ME_HEAD_COMPOSED") && atoi(getenv("ME_HEAD_COMPOSED")) == 0);
-    if (composed_on && !sp && ctx->w.head_fused_w && Hh % 16 == 0 && (dec / 2) % 64 == 0 &&
-        ((int64_t)B * Hh * Hh) % 256 == 0) {
+    ME_CHECK(!pre_image || head_composed_applies(ctx, B), ME_ERR_BAD_ARG, "head: composed features without the composed head");
+    if (head_composed_applies(ctx, B)) {
         void* h0b = site_buf(ctx, "head.h0b", bordered_bytes(B, Hh, Hh, dec / 2));
         ConvOut o;
         o.out16 = h0b, o.border16 = true;
-        conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s, false);
+        if (pre_image) {
+            o.tap_bias = ctx->w.feat_fused_b + dec / 2;
+            conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.feat_fused_w, dec / 2, 3, 1, ctx->w.feat_fused_b, o, s, false);
+        } else {
+            conv(ctx, f16b, B, Hh, Hh, dec, ctx->w.head0_w, dec / 2, 3, 1, ctx->w.head0_b, o, s, false);
+        }
         GemmParams p = base_params();
         p.M = B * Hh * Hh, p.N = 128, p.K = 9 * (dec / 2);
         p.A = h0b, p.in_Hp = Hh + 2, p.in_Wp = Hh + 2, p.Cin = dec / 2, p.out_H = Hh, p.out_W = Hh;
         p.KH = 3, p.KW = 3, p.stride = 1, p.W = ctx->w.head_fused_w, p.bias = ctx->w.head_fused_b;
-        p.head_tap_bias = ctx->w.head_fused_b + 32;
+        p.tap_bias = ctx->w.head_fused_b + 32;
         p.w2 = ctx->w.head4_w, p.b2 = ctx->w.head4_b, p.f_norm = f_norm_dev;
         p.pixels_per_image = S * S, p.out32 = depth_dev;
         p.clamp_lo = clamp ? 1e-4f : -INFINITY, p.clamp_hi = clamp ? 1e4f : INFINITY;

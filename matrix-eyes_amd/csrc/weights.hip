@@ -244,6 +244,12 @@ void build_weight_table(me_ctx* ctx) {
         ctx->head_fused_off = ctx->arena_bytes;
         ctx->arena_bytes = align_up(ctx->arena_bytes + (size_t)128 * 9 * (dec / 2) * 2 + (size_t)(32 + 9 * 32) * 4, 256);
     }
+    // derived: fusions.0.out_conv o head.0 as one 3x3 convolution (compose_features), + its f32 bias tables [dec / 2] + [9][dec / 2]
+    ctx->feat_fused_off = 0;
+    if (!ctx->split(SPLIT_HEAD)) {
+        ctx->feat_fused_off = ctx->arena_bytes;
+        ctx->arena_bytes = align_up(ctx->arena_bytes + (size_t)(dec / 2) * 9 * dec * 2 + (size_t)(10 * (dec / 2)) * 4, 256);
+    }
 }
 
 void resolve_weights(me_ctx* ctx) {
@@ -286,6 +292,8 @@ void resolve_weights(me_ctx* ctx) {
     w.head4_w = fptr(ctx, "head.4.weight"), w.head4_b = fptr(ctx, "head.4.bias");
     w.head_fused_w = ctx->head_fused_off ? (const void*)(ctx->arena + ctx->head_fused_off) : nullptr;
     w.head_fused_b = ctx->head_fused_off ? (const float*)(ctx->arena + ctx->head_fused_off + (size_t)128 * 9 * (c.dec_dim / 2) * 2) : nullptr;
+    w.feat_fused_w = ctx->feat_fused_off ? (const void*)(ctx->arena + ctx->feat_fused_off) : nullptr;
+    w.feat_fused_b = ctx->feat_fused_off ? (const float*)(ctx->arena + ctx->feat_fused_off + (size_t)(c.dec_dim / 2) * 9 * c.dec_dim * 2) : nullptr;
     w.fov_lin_w = vptr(ctx, "fov.encoder.1.weight"), w.fov_lin_b = fptr(ctx, "fov.encoder.1.bias");
     w.fov_down_w = vptr(ctx, "fov.downsample.0.weight");
     w.fov_down_b = fptr(ctx, "fov.downsample.0.bias");
@@ -328,6 +336,12 @@ void load_weight(me_ctx* ctx, const char* name, const void* data, int32_t weight
     }
     if (ctx->head_fused_off && (s.name == "head.1.weight" || s.name == "head.1.bias" || s.name == "head.2.weight" || s.name == "head.2.bias")) {
         std::vector<float>& keep = ctx->factor_keep[s.name];  // composed at finalize (compose_head)
+        keep.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) keep[i] = src.get(i);
+    }
+    if (ctx->feat_fused_off && (s.name == "decoder.fusions.0.out_conv.weight" || s.name == "decoder.fusions.0.out_conv.bias" ||
+                                s.name == "head.0.weight" || s.name == "head.0.bias")) {
+        std::vector<float>& keep = ctx->factor_keep[s.name];  // composed at finalize (compose_features)
         keep.resize((size_t)n);
         for (int64_t i = 0; i < n; ++i) keep[i] = src.get(i);
     }
@@ -421,6 +435,47 @@ void load_checkpoint_pt(me_ctx* ctx, const char* path) {
     finalize_weights(ctx);
 }
 
+// A factor of a composed layer in the checkpoint's layout: the host copy load_weight kept, or -- when the arena came by
+// me_weights_adopt / me_bcast_weights and only some other factor was reloaded -- read back from its packed arena slot (the
+// 16-bit value the un-composed path would use), so that composed weights never lag behind a factor loaded later.
+static const std::vector<float>& fetch_factor(me_ctx* ctx, const std::string& name) {
+    auto it = ctx->factor_keep.find(name);
+    if (it != ctx->factor_keep.end()) return it->second;
+    const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
+    auto from16 = [&](uint16_t h) {
+        if (!to_bf16) return half_to_float(h);
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    const WeightSlot& s = ctx->slots[ctx->slot_by_name.at(name)];
+    std::vector<float> out((size_t)s.numel());
+    if (s.kind == PK_VEC_F32) {
+        ME_HIP(hipMemcpy(out.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> raw(s.bytes / 2);
+        ME_HIP(hipMemcpy(raw.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
+        const int64_t Dd = s.dup ? 2 : 1;
+        if (s.kind == PK_CONVT_16) {  // [(q*Cout + co)][Dd * Cin] -> [Cin][Cout][q]
+            const int64_t Cin = s.dims[0], Cout = s.dims[1];
+            for (int64_t ci = 0; ci < Cin; ++ci)
+                for (int64_t co = 0; co < Cout; ++co)
+                    for (int64_t q = 0; q < 4; ++q) out[(ci * Cout + co) * 4 + q] = from16(raw[(q * Cout + co) * Dd * Cin + ci]);
+        } else if (s.kind == PK_CONV_16) {  // [Cout][kk][Dd * Cin] -> [Cout][Cin][kk]
+            const int64_t Cout = s.dims[0], Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
+            for (int64_t co = 0; co < Cout; ++co)
+                for (int64_t ci = 0; ci < Cin; ++ci)
+                    for (int64_t t = 0; t < kk; ++t) out[(co * Cin + ci) * kk + t] = from16(raw[(co * kk + t) * Dd * Cin + ci]);
+        } else {  // PK_MAT_16 [N][Dd * K] -> [N][K]
+            const int64_t N = s.dims[0], K = s.numel() / N;
+            for (int64_t r = 0; r < N; ++r)
+                for (int64_t k = 0; k < K; ++k) out[r * K + k] = from16(raw[r * Dd * K + k]);
+        }
+    }
+    return ctx->factor_keep.emplace(name, std::move(out)).first->second;
+}
+
 // decoder.rs:95-101: `deconv` (ConvTranspose 2x2 stride 2, no bias) then `out_conv` (1x1 + bias) with nothing
 // between them -- one linear map per output position q = (dy, dx): W'_q[co2][ci] = sum_co W_out[co2][co] *
 // W_deconv[ci][co][q].  Composed in f64 from the checkpoint's values and stored as a 16-bit hi + lo pair, so the
@@ -439,28 +494,6 @@ static void compose_fusion_out(me_ctx* ctx) {
         memcpy(&f, &u, 4);
         return f;
     };
-    // A factor without a host copy (the arena came by me_weights_adopt / me_bcast_weights, then ONE of the two was
-    // reloaded): read it back from its packed arena slot in the checkpoint's layout, so that the composed weights
-    // never lag behind a factor loaded later.  The slot holds the 16-bit value the two-launch path would use.
-    auto from_arena = [&](const std::string& name) {
-        const WeightSlot& s = ctx->slots[ctx->slot_by_name.at(name)];
-        std::vector<uint16_t> raw(s.bytes / 2);
-        ME_HIP(hipMemcpy(raw.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
-        std::vector<float> out((size_t)s.numel());
-        const int64_t Dd = s.dup ? 2 : 1;
-        if (s.kind == PK_CONVT_16) {  // [(q*Cout + co)][Dd * Cin] -> [Cin][Cout][q]
-            const int64_t Cin = s.dims[0], Cout = s.dims[1];
-            for (int64_t ci = 0; ci < Cin; ++ci)
-                for (int64_t co = 0; co < Cout; ++co)
-                    for (int64_t q = 0; q < 4; ++q)
-                        out[(ci * Cout + co) * 4 + q] = from16(raw[(q * Cout + co) * Dd * Cin + ci]);
-        } else {  // PK_MAT_16 [N][Dd * K] -> [N][K]
-            const int64_t N = s.dims[0], K = s.numel() / N;
-            for (int64_t r = 0; r < N; ++r)
-                for (int64_t k = 0; k < K; ++k) out[r * K + k] = from16(raw[r * Dd * K + k]);
-        }
-        return out;
-    };
     for (int i = 1; i < 5; ++i) {
         const std::string f = "decoder.fusions." + std::to_string(i) + ".";
         const std::string dn = f + "deconv.weight", on = f + "out_conv.weight";
@@ -469,9 +502,7 @@ static void compose_fusion_out(me_ctx* ctx) {
         if (d == ctx->factor_keep.end() && o == ctx->factor_keep.end()) continue;  // nothing reloaded: arena's own
         if (!ctx->slots[ctx->slot_by_name.at(dn)].loaded || !ctx->slots[ctx->slot_by_name.at(on)].loaded)
             continue;  // finalize reports the missing one
-        if (d == ctx->factor_keep.end()) d = ctx->factor_keep.emplace(dn, from_arena(dn)).first;
-        if (o == ctx->factor_keep.end()) o = ctx->factor_keep.emplace(on, from_arena(on)).first;
-        const std::vector<float>&Wd = d->second, &Wo = o->second;  // [ci][co][q], [co2][co]
+        const std::vector<float>&Wd = fetch_factor(ctx, dn), &Wo = fetch_factor(ctx, on);  // [ci][co][q], [co2][co]
         std::vector<uint16_t> packed((size_t)(4 * D) * (3 * D));
         std::vector<double> wq((size_t)D * D), acc((size_t)D);
         for (int64_t q = 0; q < 4; ++q) {
@@ -521,43 +552,10 @@ static void compose_head(me_ctx* ctx) {
     if (!any) return;  // nothing (re)loaded on this context: the arena's own composition (me_weights_adopt / broadcast)
     for (const char* nm : names)
         if (!ctx->slots[ctx->slot_by_name.at(nm)].loaded) return;  // finalize reports the missing one
-    auto from16 = [&](uint16_t h) {
-        if (!to_bf16) return half_to_float(h);
-        const uint32_t u = (uint32_t)h << 16;
-        float f;
-        memcpy(&f, &u, 4);
-        return f;
-    };
-    // a factor without a host copy (the arena was adopted, then some head tensor reloaded): back from its packed slot
-    auto fetch = [&](const std::string& name) -> const std::vector<float>& {
-        auto it = ctx->factor_keep.find(name);
-        if (it != ctx->factor_keep.end()) return it->second;
-        const WeightSlot& s = ctx->slots[ctx->slot_by_name.at(name)];
-        std::vector<float> out((size_t)s.numel());
-        if (s.kind == PK_VEC_F32) {
-            ME_HIP(hipMemcpy(out.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
-        } else {
-            std::vector<uint16_t> raw(s.bytes / 2);
-            ME_HIP(hipMemcpy(raw.data(), ctx->arena + s.offset, s.bytes, hipMemcpyDeviceToHost));
-            const int64_t Dd = s.dup ? 2 : 1;
-            if (s.kind == PK_CONVT_16) {  // [(q*Cout + co)][Dd * Cin] -> [Cin][Cout][q]
-                const int64_t Cin = s.dims[0], Cout = s.dims[1];
-                for (int64_t ci = 0; ci < Cin; ++ci)
-                    for (int64_t co = 0; co < Cout; ++co)
-                        for (int64_t q = 0; q < 4; ++q) out[(ci * Cout + co) * 4 + q] = from16(raw[(q * Cout + co) * Dd * Cin + ci]);
-            } else {  // PK_CONV_16 [Cout][kk][Dd * Cin] -> [Cout][Cin][kk]
-                const int64_t Cout = s.dims[0], Cin = s.dims[1], kk = s.dims[2] * s.dims[3];
-                for (int64_t co = 0; co < Cout; ++co)
-                    for (int64_t ci = 0; ci < Cin; ++ci)
-                        for (int64_t t = 0; t < kk; ++t) out[(co * Cin + ci) * kk + t] = from16(raw[(co * kk + t) * Dd * Cin + ci]);
-            }
-        }
-        return ctx->factor_keep.emplace(name, std::move(out)).first->second;
-    };
-    const std::vector<float>& Wt = fetch("head.1.weight");  // [ci][c][dy][dx]
-    const std::vector<float>& bT = fetch("head.1.bias");    // [c]
-    const std::vector<float>& W3 = fetch("head.2.weight");  // [co][c][ky][kx]
-    const std::vector<float>& b3 = fetch("head.2.bias");    // [co]
+    const std::vector<float>& Wt = fetch_factor(ctx, "head.1.weight");  // [ci][c][dy][dx]
+    const std::vector<float>& bT = fetch_factor(ctx, "head.1.bias");    // [c]
+    const std::vector<float>& W3 = fetch_factor(ctx, "head.2.weight");  // [co][c][ky][kx]
+    const std::vector<float>& b3 = fetch_factor(ctx, "head.2.bias");    // [co]
     std::vector<double> Wp((size_t)128 * 9 * Cm, 0.0);      // [(phase * 32 + co)][tap][ci]
     std::vector<double> w3row((size_t)Cm);
     for (int dy = 0; dy < 2; ++dy)
@@ -594,6 +592,55 @@ static void compose_head(me_ctx* ctx) {
     }
     ME_HIP(hipMemcpy(ctx->arena + ctx->head_fused_off, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     ME_HIP(hipMemcpy(ctx->arena + ctx->head_fused_off + packed.size() * 2, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+}
+
+// decoder.rs:101 + mod.rs:323-326: the last fusion block's out_conv (1x1, dec -> dec, bias) feeds head[0] (Conv2d 3x3, dec -> dec / 2,
+// padding 1, bias) with nothing between them -- ONE 3x3 convolution of out_conv's INPUT v (the residual unit's output):
+//   head0(out_conv(v))[y][x][n] = b'[n] + sum_{tap, k} v[y + ty][x + tx][k] * W''[n][tap][k],   W''[n][tap][k] = sum_c W0[n][c][tap] Wo[c][k],
+//   b'[n] = b0[n] + sum_tap Cb[tap][n],   Cb[tap][n] = sum_c W0[n][c][tap] bo[c].
+// The [B, dec, 768, 768] feature map and its 1x1 launch (0.9 GB of traffic) go; the residual unit's last convolution writes v as
+// the zero-bordered 16-bit operand directly.  head[0] pads out_conv's OUTPUT with zeros, so a tap that falls outside the map
+// must not contribute bo either: the epilogue takes that tap's Cb share out of the bias again at the image border (the v part
+// vanishes by itself, v being zero-bordered) -- GemmParams::tap_bias.  Composed in f64 from the checkpoint's values, rounded
+// once to the operand type.  Layout = head.0.weight's own ([dec / 2][9][dec]); tables f32 [dec / 2] + [9][dec / 2].
+static void compose_features(me_ctx* ctx) {
+    if (!ctx->feat_fused_off) return;
+    const int64_t D = ctx->cfg.dec_dim, Co = D / 2;
+    const bool to_bf16 = ctx->dtype == ME_DTYPE_BF16;
+    auto to16 = [&](float f) { return to_bf16 ? float_to_bf16(f) : float_to_half(f); };
+    const char* names[4] = {"decoder.fusions.0.out_conv.weight", "decoder.fusions.0.out_conv.bias", "head.0.weight", "head.0.bias"};
+    bool any = false;
+    for (const char* nm : names) any = any || ctx->factor_keep.count(nm);
+    if (!any) return;  // nothing (re)loaded on this context: the arena's own composition (me_weights_adopt / broadcast)
+    for (const char* nm : names)
+        if (!ctx->slots[ctx->slot_by_name.at(nm)].loaded) return;  // finalize reports the missing one
+    const std::vector<float>& Wo = fetch_factor(ctx, names[0]);  // [c][k]
+    const std::vector<float>& bo = fetch_factor(ctx, names[1]);  // [c]
+    const std::vector<float>& W0 = fetch_factor(ctx, names[2]);  // [n][c][tap]
+    const std::vector<float>& b0 = fetch_factor(ctx, names[3]);  // [n]
+    std::vector<uint16_t> packed((size_t)Co * 9 * D);
+    std::vector<float> tab((size_t)10 * Co, 0.f);
+    std::vector<double> acc((size_t)D);
+    for (int64_t n = 0; n < Co; ++n) {
+        double bsum = (double)b0[n];
+        for (int t = 0; t < 9; ++t) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            double cb = 0.0;
+            for (int64_t c = 0; c < D; ++c) {
+                const double w = (double)W0[(n * D + c) * 9 + t];
+                const float* row = &Wo[(size_t)c * D];
+                for (int64_t k = 0; k < D; ++k) acc[k] += w * (double)row[k];
+                cb += w * (double)bo[c];
+            }
+            uint16_t* dst = &packed[((size_t)n * 9 + t) * D];
+            for (int64_t k = 0; k < D; ++k) dst[k] = to16((float)acc[k]);
+            tab[(size_t)Co + t * Co + n] = (float)cb;
+            bsum += cb;
+        }
+        tab[n] = (float)bsum;
+    }
+    ME_HIP(hipMemcpy(ctx->arena + ctx->feat_fused_off, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    ME_HIP(hipMemcpy(ctx->arena + ctx->feat_fused_off + packed.size() * 2, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
 }
 
 // ME_DTYPE_FP8: quantise qkv / proj / fc1 / fc2 of the three ViTs from the packed f16 arena (the checkpoint's values)
@@ -647,6 +694,7 @@ void finalize_weights(me_ctx* ctx) {
              missing.c_str(), n > 8 ? ", ..." : "");
     compose_fusion_out(ctx);
     compose_head(ctx);
+    compose_features(ctx);
     build_fp8_weights(ctx);
     ctx->finalized = true;
     ctx->drop_graph(), ++ctx->weights_generation;

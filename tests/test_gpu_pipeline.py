@@ -660,6 +660,57 @@ def test_composed_head_equals_the_three_layers(tmp_path):
     assert frame_err < 3 * inner_err + 1e-3      # a missing border term would be of the order of the bias: 10 - 100 x this
 
 
+_FEAT_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import matrix_eyes_amd as m
+from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+cfg = m.ModelConfig.tiny()
+w = dict(synthetic_checkpoint(cfg))
+# an out_conv bias large enough that a wrong border term would show: head[0] pads out_conv's OUTPUT with zeros, so the composed
+# convolution takes the share of every tap that falls into that padding out of its bias
+import torch
+w["decoder.fusions.0.out_conv.bias"] = torch.linspace(-0.5, 0.5, cfg.dec_dim)
+ctx = m.Context(0, "f16", cfg)
+ctx.load_state_dict(w)
+rgb = synthetic_images(2, cfg.img_size, "structured", seed=5)
+d = ctx.extract_depth(rgb, 1.0)
+canon = ctx.extract_depth(rgb, 1.0)       # repeatable
+assert np.array_equal(d, canon)
+np.save(sys.argv[2], d)
+"""
+
+
+def test_composed_features_equal_the_two_layers(tmp_path):
+    """VERDICT r4 item 4a, by composition instead of a second GEMM in the epilogue.  The last fusion block's out_conv (1x1) and
+    head[0] (conv3x3) composed at load time into one 3x3 convolution of out_conv's input (weights.hip compose_features; the residual
+    unit's last convolution writes that input as the zero-bordered 16-bit operand, GemmParams::tap_bias corrects the bias on the
+    frame) against the two launches (ME_FEAT_COMPOSED=0): tiny model, a batch of two, a deliberately large out_conv bias.  The
+    maps agree to the operand roundings that differ (the feature map is no longer rounded to 16 bits, its pre-image and the composed
+    weights are), on the one-pixel frame of the half-resolution map -- two pixels of the depth map -- as well as inside."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("composed", {}), ("layers", {"ME_FEAT_COMPOSED": "0"})):
+        path = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _FEAT_CHILD, root, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path)
+    a, b = outs["composed"], outs["layers"]
+    assert np.isfinite(a).all() and a.shape == b.shape and not np.array_equal(a, b)
+    assert rel_l2(a, b) < 6e-4
+    frame = np.ones(a.shape[1:], bool)
+    frame[4:-4, 4:-4] = False     # the half-resolution frame pixel and its 3x3 neighbourhood in the head's second convolution
+    scale = np.sqrt((b ** 2).mean())
+    inner_err = np.abs(a - b)[:, ~frame].max() / scale
+    frame_err = np.abs(a - b)[:, frame].max() / scale
+    print("composed features vs two layers: rel-L2", rel_l2(a, b), "max |d| / rms inside", inner_err, "on the frame", frame_err)
+    assert frame_err < 3 * inner_err + 1e-3      # a missing border term would be of the order of the bias: 10 - 100 x this
+
+
 _LN_FALLBACK_CHILD = """
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
