@@ -108,6 +108,14 @@ int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, 
                                   int32_t seg1, int32_t seg2, const uint8_t* const W8[3], const uint8_t* const w_scale[3],
                                   const float* const bias[3], const float* const gamma[3], void* out16, uint8_t* out8,
                                   uint8_t* out8_scale, float* x32);
+/* The fp8 GEMM's residual form with the LayerNorm of the rows it updates (csrc/gemm_fp8.hip gemm_pp8t_kernel, the 352-row
+   tile): x32[M][N] += gamma * (A8 W8^T + bias) in place and LayerNorm(x32[m][:], eps) * ln_w + ln_b of the row's segment as
+   the next GEMM's MX fp8 operand (xn8 / xn_scale as in me_op_linear_residual_layernorm_fp8) -- what an ME_DTYPE_FP8
+   context's fc2 hands to the next block's qkv.  Operands as me_op_linear_fp8_segments; N in {256, 512, 1024}. */
+int32_t me_op_linear_fp8_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                                            int32_t seg1, int32_t seg2, const uint8_t* const W8[3], const uint8_t* const w_scale[3],
+                                            const float* const bias[3], const float* const gamma[3], const float* const ln_w[3],
+                                            const float* const ln_b[3], float eps, float* x32, uint8_t* xn8, uint8_t* xn_scale);
 /* me_op_attention with the output written as an MX fp8 activation operand (out8 [windows*tokens][heads*64] bytes +
    block scales; heads even): the bytes me_op_quantize_fp8 gives for me_op_attention's 16-bit output. */
 int32_t me_op_attention_fp8(me_ctx* ctx, const void* qkv16, uint8_t* out8, uint8_t* out8_scale, int32_t windows,

@@ -110,6 +110,8 @@ SIGNATURES = {
                                                C.POINTER(_vp), C.POINTER(_vp), _f32, _vp, _vp]),
     "me_op_linear_residual_layernorm_fp8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                                    C.POINTER(_vp), C.POINTER(_vp), _f32, _vp, _vp, _vp]),
+    "me_op_linear_fp8_residual_layernorm": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp),
+                                                   C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _f32, _vp, _vp, _vp]),
     "me_op_format_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp]),
     "me_calibrate": (_i32, [_vp, C.POINTER(C.c_double)]),
     "me_op_cast_to16": (_i32, [_vp, _vp, _vp, _i64]),

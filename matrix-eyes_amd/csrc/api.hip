@@ -1215,6 +1215,34 @@ int32_t me_op_linear_fp8_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, 
     ME_API_END(ctx)
 }
 
+int32_t me_op_linear_fp8_residual_layernorm(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const uint8_t* A8, const uint8_t* a_scale,
+                                            int32_t seg1, int32_t seg2, const uint8_t* const W8[3], const uint8_t* const w_scale[3],
+                                            const float* const bias[3], const float* const gamma[3], const float* const ln_w[3],
+                                            const float* const ln_b[3], float eps, float* x32, uint8_t* xn8, uint8_t* xn_scale) {
+    ME_API_BEGIN(ctx)
+    ME_CHECK(A8 && a_scale && W8 && w_scale && bias && gamma && ln_w && ln_b && x32 && xn8 && xn_scale, ME_ERR_BAD_ARG,
+             "me_op_linear_fp8_residual_layernorm: null pointer");
+    const int nseg = seg1 == 0 ? 1 : (seg2 == 0 ? 2 : 3);
+    for (int i = 0; i < nseg; ++i)
+        ME_CHECK(W8[i] && w_scale[i] && bias[i] && gamma[i] && ln_w[i] && ln_b[i], ME_ERR_BAD_ARG,
+                 "me_op_linear_fp8_residual_layernorm: row segment %d without weights", i);
+    GemmParams p = GemmParams();
+    p.M = M, p.N = N, p.K = K, p.A = A8, p.lda = K, p.a_scale = a_scale, p.a_mt = (int)cdiv(M, 128);
+    p.W = W8[0], p.w_scale = w_scale[0], p.bias = bias[0], p.ldc = N;
+    p.seg1 = seg1, p.seg2 = seg2;
+    p.W_s1 = W8[1], p.w_scale_s1 = w_scale[1], p.bias_s1 = bias[1];
+    p.W_s2 = W8[2], p.w_scale_s2 = w_scale[2], p.bias_s2 = bias[2];
+    p.clamp_lo = -INFINITY, p.clamp_hi = INFINITY;
+    p.gamma = gamma[0], p.gamma_s1 = gamma[1], p.gamma_s2 = gamma[2], p.res32 = x32, p.out32 = x32;
+    p.ln_out16 = xn8, p.ln_eps = eps, p.out8 = xn8, p.out8_scale = xn_scale, p.out8_mt = (int32_t)cdiv(M, 128);
+    p.ln_w = ln_w[0], p.ln_b = ln_b[0], p.ln_w_s1 = ln_w[1], p.ln_b_s1 = ln_b[1], p.ln_w_s2 = ln_w[2], p.ln_b_s2 = ln_b[2];
+    const size_t row_tiles = (size_t)seg_row_tiles<352>(M, seg1, seg2);
+    p.ln_stats = (unsigned long long*)site_buf(ctx, "op.ln.stats", row_tiles * (size_t)(N / 256) * 352 * 8);
+    p.ln_count = (unsigned*)site_buf(ctx, "op.ln.count." + std::to_string(N), row_tiles * 64);
+    gemm_fp8_launch(p, EPI_RESID_SCALE, ctx->stream);
+    ME_API_END(ctx)
+}
+
 int32_t me_op_linear_segments(me_ctx* ctx, int32_t M, int32_t N, int32_t K, const void* A16, int32_t seg1, int32_t seg2,
                               const void* const W16[3], const float* const bias[3], const float* const gamma[3],
                               void* out16, float* x32, int32_t act, int32_t tile_cfg) {

@@ -836,7 +836,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     }
                 }
                 if constexpr (MODE == 3) {
-                    // fp8 output (M, N multiples of 256: every row and column exists): two rows at a time, so that
+                    // fp8 output (N a multiple of 256: every column exists; rows up to Mrows): two rows at a time, so that
                     // each lane's bytes leave as one 16-byte store
                     static_assert(ITERS % 2 == 0, "row pairs");
 #pragma unroll
@@ -851,9 +851,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                                                                 v[it + u][h][2] + lc.bias[h].z, v[it + u][h][3] + lc.bias[h].w});
                                 a[4 * h] = g[0], a[4 * h + 1] = g[1], a[4 * h + 2] = g[2], a[4 * h + 3] = g[3];
                             }
-                            q[u] = quantise_granule_fp8(p, row.m + u * RPI, n, a);
+                            q[u] = quantise_granule_fp8(p, row.m + u * RPI, n, a, row.m + u * RPI < Mrows);
                         }
-                        store_granule_pair_fp8(p, row.m, row.m + RPI, n, q[0], q[1]);
+                        store_granule_pair_fp8(p, row.m, row.m + RPI, n, q[0], q[1], Mrows);
                         row.m += 2 * RPI;
                     }
                     continue;

@@ -36,7 +36,8 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // the fp8 + scales form of an epilogue granule (fc1: bias + GELU, then quantised as the next GEMM's activation
 // operand): 8 consecutive columns of one row per lane, 4 adjacent lanes share a 32-column MX block.  Returns the 8
 // bytes and stores the block's scale.
-__device__ __forceinline__ uint2 quantise_granule_fp8(const GemmParams& p, int m, int n, const float (&a)[8]) {
+// row_ok: row m exists (the tall tile's last row tile of a segment computes rows beyond it: nothing of them is stored)
+__device__ __forceinline__ uint2 quantise_granule_fp8(const GemmParams& p, int m, int n, const float (&a)[8], bool row_ok = true) {
     float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(a[e]));
@@ -48,20 +49,21 @@ __device__ __forceinline__ uint2 quantise_granule_fp8(const GemmParams& p, int m
     uint2 v;
     v.x = pack_fp8x4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
     v.y = pack_fp8x4(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
-    if ((n & 31) == 0) p.out8_scale[a_scale_index(m, n >> 5, p.out8_mt)] = (uint8_t)sb;
+    if ((n & 31) == 0 && row_ok) p.out8_scale[a_scale_index(m, n >> 5, p.out8_mt)] = (uint8_t)sb;
     return v;
 }
 // Two rows' granules leave as ONE 16-byte store per lane (8-byte stores run at less than half the rate, gemm_core.h):
 // lanes l and l ^ 1 hold adjacent granules (columns n and n +- 8) of the same rows m0 and m1; the even lane stores
 // both granules of row m0, the odd lane both of row m1.
-__device__ __forceinline__ void store_granule_pair_fp8(const GemmParams& p, int m0, int m1, int n, uint2 q0, uint2 q1) {
+__device__ __forceinline__ void store_granule_pair_fp8(const GemmParams& p, int m0, int m1, int n, uint2 q0, uint2 q1, int m_end) {
     const bool odd = (n & 8) != 0;
     const uint2 send = odd ? q0 : q1;
     uint2 recv;
     recv.x = __builtin_amdgcn_update_dpp(0, send.x, 0xB1, 0xF, 0xF, true);
     recv.y = __builtin_amdgcn_update_dpp(0, send.y, 0xB1, 0xF, 0xF, true);
     const uint4 o = odd ? make_uint4(recv.x, recv.y, q1.x, q1.y) : make_uint4(q0.x, q0.y, recv.x, recv.y);
-    *reinterpret_cast<uint4*>(p.out8 + (int64_t)(odd ? m1 : m0) * p.ldc + (n & ~15)) = o;
+    const int m = odd ? m1 : m0;
+    if (m < m_end) *reinterpret_cast<uint4*>(p.out8 + (int64_t)m * p.ldc + (n & ~15)) = o;
 }
 
 }  // namespace me

@@ -287,6 +287,7 @@ struct MergedVit {
     float* tok;
     char *xn, *qkv, *att, *hid, *fin16;
     bool xn_is_norm1 = false;  // xn already holds norm1 of the block about to run (written by the block before)
+    bool xn_is_norm1_fp8 = false;  // fp8 contexts: xn / xn_s hold norm1 of the block about to run as MX fp8 (the fp8 fc2's epilogue)
     bool xn_is_norm2_fp8 = false;  // fp8 contexts: xn / xn_s hold norm2 as MX fp8 (written by the projection's epilogue)
     float* fin32 = nullptr;
     // ME_DTYPE_FP8: xn and hid hold e4m3 bytes, with their block scales (activation layout, Rtot / 128 tiles)
@@ -491,8 +492,10 @@ struct MergedVit {
     }
 
     // the MX fp8 form of gemm_all / resid_all (gemm_fp8.hip): A = xn or hid as e4m3 + block scales
-    void gemm8(const void* A8, const uint8_t* As, int K, int N, const VitBlockW& b0, const VitBlockW& b1,
-               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2, 3 proj*/, bool hid16_out = false) {
+    // ln (fc2 / proj only): also write LayerNorm(ln) of the updated rows into xn / xn_s as MX fp8 -- the tall tile's residual
+    // epilogue; returns true when it did
+    bool gemm8(const void* A8, const uint8_t* As, int K, int N, const VitBlockW& b0, const VitBlockW& b1,
+               const VitBlockW& b2, int which /*0 qkv, 1 fc1, 2 fc2, 3 proj*/, bool hid16_out = false, const LnSet* ln = nullptr) {
         GemmParams p = base_params();
         auto w8 = [&](const VitBlockW& b) { return which == 0 ? b.qkv_w8 : (which == 1 ? b.fc1_w8 : (which == 2 ? b.fc2_w8 : b.proj_w8)); };
         auto ws = [&](const VitBlockW& b) { return which == 0 ? b.qkv_ws : (which == 1 ? b.fc1_ws : (which == 2 ? b.fc2_ws : b.proj_ws)); };
@@ -515,8 +518,21 @@ struct MergedVit {
             gemm_fp8_launch(p, EPI_STORE, s);
         } else {
             p.gamma = gamma(b0), p.gamma_s1 = gamma(b1), p.gamma_s2 = gamma(b2), p.res32 = tok, p.out32 = tok;
+            static const bool fp8_lnf = !(getenv("ME_FP8_LN_FUSE") && atoi(getenv("ME_FP8_LN_FUSE")) == 0);
+            if (ln && fp8_lnf && ln_fusable()) {
+                const int C = ctx->C();
+                const size_t row_tiles = (size_t)seg_row_tiles<352>((int)Rtot, (int)seg1, (int)seg2);
+                p.ln_out16 = xn, p.ln_eps = ctx->cfg.ln_eps;
+                p.out8 = (uint8_t*)xn, p.out8_scale = xn_s, p.out8_mt = (int)(Rtot / 128);
+                p.ln_w = ln->w0, p.ln_b = ln->b0, p.ln_w_s1 = ln->w1, p.ln_b_s1 = ln->b1, p.ln_w_s2 = ln->w2, p.ln_b_s2 = ln->b2;
+                p.ln_stats = (unsigned long long*)site_buf(ctx, "vitm.ln.stats", row_tiles * (size_t)(C / 256) * 352 * 8);
+                p.ln_count = (unsigned*)site_buf(ctx, "vitm.ln.count", row_tiles * 64);   // zero when allocated, never reset
+                gemm_fp8_launch(p, EPI_RESID_SCALE, s);
+                return true;
+            }
             gemm_fp8_launch(p, EPI_RESID_SCALE, s);
         }
+        return false;
     }
 
     // vit.rs:163-170 Block::forward for the three ViTs
@@ -532,7 +548,10 @@ struct MergedVit {
             const int windows = W0 + W1 * (fov ? 2 : 1);
             set_ln(b1.ln1_w, b1.ln1_b, b2.ln1_w, b2.ln1_b);
             if (q8) {
-                layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                // norm1 as MX fp8: written by the previous block's fp8 fc2 where the LayerNorm rides in its residual epilogue
+                if (!xn_is_norm1_fp8)
+                    layernorm_fp8_launch(tok, b0.ln1_w, b0.ln1_b, (uint8_t*)xn, xn_s, Rtot, C, ctx->cfg.ln_eps, s, &segs);
+                xn_is_norm1_fp8 = false;
                 gemm8(xn, xn_s, C, 3 * C, b0, b1, b2, 0);
             } else {
                 layernorm_launch(tok, b0.ln1_w, b0.ln1_b, xn, nullptr, Rtot, C, ctx->cfg.ln_eps, ctx->dtype, s, &segs);
@@ -549,7 +568,9 @@ struct MergedVit {
                 } else {
                     attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, att8, att_s, Rtot / 128, true);
                 }
-                gemm8(att8, att_s, C, C, b0, b1, b2, 3);
+                // ... and its residual epilogue norm2 as fc1's fp8 operand (the tall fp8 tile)
+                const LnSet ln2{b0.ln2_w, b0.ln2_b, b1.ln2_w, b1.ln2_b, b2.ln2_w, b2.ln2_b};
+                xn_is_norm2_fp8 = gemm8(att8, att_s, C, C, b0, b1, b2, 3, false, f18 ? &ln2 : nullptr);
             } else {
                 attention_launch(qkv, att, windows, T, heads, ctx->dtype, s, &segs, nullptr, nullptr, 0, true);
                 // the 16-bit projection's residual epilogue writes norm2 as fc1's MX fp8 operand (gemm_core.h resid_ln_epilogue)
@@ -574,7 +595,13 @@ struct MergedVit {
                     quantize_f16_to_fp8_launch(hid, q, hid_s, Rtot, 4 * C, 0, s);
                     h8 = q;
                 }
-                gemm8(h8, hid_s, 4 * C, C, b0, b1, b2, 2);
+                LnSet next;
+                const bool fuse_next = q8 && i + 1 < ctx->cfg.depth;  // the next block's qkv reads norm1 as fp8
+                if (fuse_next) {
+                    const VitBlockW &n0 = p0.blocks[i + 1], &n1 = p1.blocks[i + 1], &n2 = p2.blocks[i + 1];
+                    next = LnSet{n0.ln1_w, n0.ln1_b, n1.ln1_w, n1.ln1_b, n2.ln1_w, n2.ln1_b};
+                }
+                xn_is_norm1_fp8 = gemm8(h8, hid_s, 4 * C, C, b0, b1, b2, 2, false, fuse_next ? &next : nullptr);
             } else {
                 resid_all(hid, 4 * C, b0.fc2_w, b0.fc2_b, b0.ls2, b1.fc2_w, b1.fc2_b, b1.ls2, b2.fc2_w, b2.fc2_b, b2.ls2);
             }

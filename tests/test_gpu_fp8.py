@@ -461,3 +461,148 @@ def test_linear_residual_layernorm_fp8_fused(shape):
     ctx.synchronize()
     assert torch.equal(again, fused) and torch.equal(xn8b, xn8[:M]) and torch.equal(xsb, xs)
     assert ctx.status_flags() == 0
+
+
+def _fp8_problem(ctx, g, M, N, K, nseg):
+    """quantised operands of an fp8 linear over `nseg` row segments + the dequantised f64 matrices"""
+    a16 = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 0.5)).half().cuda()
+    a8, asc = _quantize_gpu(ctx, a16, 0)
+    A = _dequant(a8.cpu().view(E4M3), _scale_table(asc, M, K, 0)).cuda()
+    wsets = []
+    for _ in range(nseg):
+        w16 = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+        w8, wsc = _quantize_gpu(ctx, w16, 1)
+        W = _dequant(w8.cpu().view(E4M3), _scale_table(wsc, N, K, 1)).cuda()
+        wsets.append((w8, wsc, W, torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) * 0.15 + 0.05).cuda()))
+    while len(wsets) < 3:
+        wsets.append(wsets[0])
+    return a8, asc, A, wsets
+
+
+@pytest.mark.parametrize("shape", [(21760, 1024, 4096, 768, 1536), (21760, 4096, 1024, 768, 1536), (21760, 3072, 1024, 768, 1536),
+                                   (5120, 1024, 1024, 0, 0)])
+def test_linear_fp8_tall_tile_is_bit_identical_to_the_256_row_tile(shape):
+    """gemm_pp8t_kernel (352-row tile, csrc/gemm_fp8.hip) against gemm_pp8_kernel on the same operands, the
+    three epilogues, at the step's shapes with its three row segments: the same K order per output element, so the same bits.
+    ME_FP8_TALL = 0 / 1 picks the tile (read per launch)."""
+    import os
+    M, N, K, seg1, seg2 = shape
+    ctx = ctx_for("tiny", "f16")
+    g = torch.Generator().manual_seed(M + N + K + 3)
+    a8, asc, A, wsets = _fp8_problem(ctx, g, M, N, K, 3 if seg2 else 1)
+    VP = C.c_void_p * 3
+    W8 = VP(*[w[0].data_ptr() for w in wsets]); WS = VP(*[w[1].data_ptr() for w in wsets])
+    BI = VP(*[w[3].data_ptr() for w in wsets]); GA = VP(*[w[4].data_ptr() for w in wsets])
+    x0 = torch.randn(M, N, generator=g).cuda()
+    got = {}
+    old = os.environ.get("ME_FP8_TALL")
+    try:
+        for tall in ("0", "1"):
+            os.environ["ME_FP8_TALL"] = tall
+            out16 = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+            o8 = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+            osc = torch.zeros(M * N // 32, dtype=torch.uint8, device="cuda")
+            x32 = x0.clone()
+            torch.cuda.synchronize()
+            ctx._check(ctx.lib.me_op_linear_fp8_segments(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, None,
+                                                         ptr(out16), None, None, None))
+            ctx._check(ctx.lib.me_op_linear_fp8_segments(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, None,
+                                                         None, ptr(o8), ptr(osc), None))
+            ctx._check(ctx.lib.me_op_linear_fp8_segments(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, GA,
+                                                         None, None, None, ptr(x32)))
+            ctx.synchronize()
+            got[tall] = (out16, o8, osc, x32)
+    finally:
+        if old is None:
+            os.environ.pop("ME_FP8_TALL", None)
+        else:
+            os.environ["ME_FP8_TALL"] = old
+    assert bool(torch.isfinite(got["1"][0]).all())
+    for a, b in zip(got["0"], got["1"]):
+        assert torch.equal(a, b)
+    # and against the f64 product of the dequantised operands (the first segment's rows)
+    hi = seg1 if seg1 else M
+    ref = A[:hi] @ wsets[0][2].T + wsets[0][3].double()
+    err = (got["1"][0][:hi].double() - ref).abs()
+    assert float((err / (ref.abs() * 2.0 ** -10 + 2e-3 * ref.abs().mean())).max()) < 1.0
+
+
+@pytest.mark.parametrize("shape", [(1000, 1024, 256, 0, 0), (1536, 512, 512, 512, 1024), (2300, 1024, 1024, 768, 0),
+                                   (21760, 1024, 4096, 768, 1536)])
+def test_linear_fp8_residual_layernorm_fused(shape):
+    """The fp8 fc2 with the next block's norm1 in its residual epilogue (gemm_pp8t_kernel<..., LNF>): x32 is bit for bit the plain
+    fp8 residual launch's (ragged M included: the tall tile clamps its rows); the bytes and scales are what me_op_layernorm_fp8
+    gives on those x32 rows up to the last bit of a few elements; dequantised they sit within half an e4m3 step of an fp64
+    LayerNorm; rows behind M are not written; a second launch from the same input gives the same bytes."""
+    import os
+    M, N, K, seg1, seg2 = shape
+    ctx = ctx_for("tiny", "f16")
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    nseg = 3 if seg2 else (2 if seg1 else 1)
+    a8, asc, A, wsets = _fp8_problem(ctx, g, M, N, K, nseg)
+    lw = [(1.0 + 0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    lb = [(0.1 * torch.randn(N, generator=g)).cuda() for _ in range(3)]
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    W8 = arr([w[0] for w in wsets]); WS = arr([w[1] for w in wsets]); BI = arr([w[3] for w in wsets]); GA = arr([w[4] for w in wsets])
+    x0 = torch.randn(M, N, generator=g) * 2.0
+    x0[:, 7] += 40.0
+    x0[::3] *= 10.0
+    x0 = x0.cuda()
+    plain, fused = x0.clone(), x0.clone()
+    mt = (M + 127) // 128
+    xn8 = torch.full((M + 1, N), 0x55, dtype=torch.uint8, device="cuda")       # a guard row behind the output
+    xs = torch.zeros(mt * 128 * N // 32, dtype=torch.uint8, device="cuda")
+    eps = 1e-5
+    old = os.environ.get("ME_FP8_TALL")
+    os.environ["ME_FP8_TALL"] = "1"
+    try:
+        torch.cuda.synchronize()
+        ctx._check(ctx.lib.me_op_linear_fp8_segments(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, GA, None, None,
+                                                     None, ptr(plain)))
+    finally:
+        if old is None:
+            os.environ.pop("ME_FP8_TALL", None)
+        else:
+            os.environ["ME_FP8_TALL"] = old
+    ctx._check(ctx.lib.me_op_linear_fp8_residual_layernorm(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, GA,
+                                                           arr(lw), arr(lb), eps, ptr(fused), ptr(xn8), ptr(xs)))
+    ctx.synchronize()
+    assert ctx.status_flags() == 0
+    assert torch.equal(fused, plain)
+    assert bool((xn8[M] == 0x55).all())
+    bounds = [0, seg1 if seg1 else M, (seg2 if seg2 else M) if seg1 else M, M]
+    # the residual update itself against f64
+    want = x0.double()
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi > lo:
+            want[lo:hi] += wsets[i][4].double() * (A[lo:hi] @ wsets[i][2].T + wsets[i][3].double())
+    assert float((fused.double() - want).abs().max() / want.abs().max()) < 3e-5
+    ref = torch.empty(M, N, dtype=torch.float64)
+    xd = fused.double().cpu()
+    for i in range(3):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi > lo:
+            ref[lo:hi] = F.layer_norm(xd[lo:hi], (N,), lw[i].double().cpu(), lb[i].double().cpu(), eps)
+    sb = _scale_table(xs, M, N, 0)
+    diff = (sb.int() - _scale_bytes(ref.float().abs().reshape(M, N // 32, 32).amax(2)).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
+    got = _dequant(xn8[:M].cpu().view(E4M3), sb)
+    blockmax = ref.abs().reshape(M, N // 32, 32).amax(2, keepdim=True).expand(-1, -1, 32).reshape(M, N)
+    assert float(((got - ref).abs() / blockmax).max()) <= 2.0 ** -4 * 1.01
+    if seg1 == 0:   # the stand-alone LayerNorm -> fp8 kernel on the same rows (one weight set: no segments)
+        y8 = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+        ys = torch.zeros_like(xs)
+        ctx._check(ctx.lib.me_op_layernorm_fp8(ctx.handle, ptr(fused), ptr(lw[0]), ptr(lb[0]), ptr(y8), ptr(ys), M, N, eps))
+        ctx.synchronize()
+        assert float((ys != xs).float().mean()) < 1e-3
+        assert float((y8 != xn8[:M]).float().mean()) < 2e-3
+    again = x0.clone()
+    xn8b = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+    xsb = torch.zeros_like(xs)
+    torch.cuda.synchronize()
+    ctx._check(ctx.lib.me_op_linear_fp8_residual_layernorm(ctx.handle, M, N, K, ptr(a8), ptr(asc), seg1, seg2, W8, WS, BI, GA,
+                                                           arr(lw), arr(lb), eps, ptr(again), ptr(xn8b), ptr(xsb)))
+    ctx.synchronize()
+    assert torch.equal(again, fused) and torch.equal(xn8b, xn8[:M]) and torch.equal(xsb, xs)
+    assert ctx.status_flags() == 0
