@@ -58,12 +58,13 @@ def describe(op, cfg):
         resid = op == "fc2_8"
         out = PROBE_M * n * (8 if resid else (2 if op == "qkv8" else 1 + 1 / 32))
         bytes_ = PROBE_M * k * (1 + 1 / 32) + n * k * (1 + 1 / 32) + out + n * 4 * (2 if resid else 1)
-        return f"gemm_kernel<fp8,256x256x128/8w-pp,plain,{'resid_scale' if resid else 'store'}>", int(bytes_)
+        # (fc2 at one image runs on the 352-row tile, gemm_fp8.hip fp8_tall_wins; the probe launches the plain residual form)
+        return f"gemm_kernel<fp8,{'352' if resid else '256'}x256x128/8w-pp,plain,{'resid_scale' if resid else 'store'}>", int(bytes_)
     if op == "conv768":   # 16-bit bordered input, weights, f32 residual in, f32 + 16-bit out
         px = 768 * 768
         return f"gemm_kernel<f16,{CFG_NAMES[cfg]},conv,store>", 770 * 770 * 256 * 2 + 256 * 2304 * 2 + px * 256 * (4 + 4 + 2)
     return "attention2_kernel", 35 * 577 * (3072 + 1024) * 2
-KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_ring_kernel", "gemm_8ph_kernel", "conv_halo_kernel",
+KERNEL_KEYS = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp8_kernel", "gemm_pp8t_kernel", "gemm_ring_kernel", "gemm_8ph_kernel", "conv_halo_kernel",
                "attention_kernel", "attention2_kernel", "attention3_kernel")
 
 
