@@ -270,6 +270,13 @@ struct GemmParams {
     // persistent kernels: at most this many workgroups (a multiple of 8), so that a launch on another stream finds
     // free CUs beside this one; 0: as many as are resident
     int32_t grid_cap;
+    // Deterministic split-K (gemm_core.h gemm_kernel<..., SPLITK>; the 128x128 tile, EPI_STORE): split_k > 1 work items per tile,
+    // each over a K range; every one writes its f32 partial (accumulator layout) to splitk_ws[(tile * split_k + s)][BM * BN] and
+    // counts its arrival in splitk_cnt[tile] (zero before the launch; the last arriver resets it); the LAST arriver sums the
+    // partials in split order -- its own included, so the result does not depend on who is last -- and runs the epilogue.
+    int32_t split_k;
+    float* splitk_ws;
+    unsigned* splitk_cnt;
     // Tile queue of the launch stream (gemm_launch fills it in), or null for the static tile order.
     // Word 32 x: next-tile ticket of XCD x (x < 8), word 256: exited workgroups -- one 128-byte line each
     // (on one line the 512 prologue draws of a launch serialise in a single L2 channel).

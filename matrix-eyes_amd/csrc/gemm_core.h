@@ -1359,7 +1359,7 @@ struct SchedPin<G, NI, G> {
 // bid, bid + gridDim.x, ... (the same XCD every time).  The K loop runs as ONE stream across tile
 // boundaries: the last slab iteration of a tile stages the first slab of the next tile, so neither the
 // next tile's first-load latency nor the drain of this tile's epilogue stores is exposed.
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -1382,17 +1382,29 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    // SPLITK: a work item is (tile, K range); item vb = tile * S + s, so a tile's S items sit on neighbouring workgroups
+    const int S = SPLITK ? p.split_k : 1;
+    const int nitems = ntiles * S;
 
     // ---- per-lane source pointers for the staging loads of one tile ----
     const int srow = lane >> 3;  // row within an 8-row LDS-DMA piece
     const int sslot = lane & 7;  // 16-byte slot written by this lane
     struct TileSrc {
         int m0, n0;
+        int tile, kb, ke;  // SPLITK: the tile and the slab range [kb, ke) of this item
         const char* a[A_ITERS];
         const char* w[B_ITERS];
     };
+    const int nk = p.K / 64;
     auto setup = [&](TileSrc& t, int vb) {
-        tile_origin<BM, BN>(p, vb, ntiles, t.m0, t.n0);
+        if constexpr (SPLITK) {
+            t.tile = vb / S;
+            const int ks = vb - t.tile * S;
+            t.kb = (int)((int64_t)ks * nk / S), t.ke = (int)((int64_t)(ks + 1) * nk / S);
+        } else {
+            t.tile = vb, t.kb = 0, t.ke = nk;
+        }
+        tile_origin<BM, BN>(p, t.tile, ntiles, t.m0, t.n0);
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int row = (i * NW + wave) * 8 + srow;
@@ -1415,7 +1427,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
         }
     };
 
-    const int nk = p.K / 64;
     // Staging of slab kt of tile t into LDS buffer buf (slabs are staged in order: kt = 0 rewinds the taps)
     SlabWalk<AMODE> walk;
     walk.init(p);
@@ -1444,8 +1455,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     int vb = blockIdx.x;
     TileSrc cur, nxt;
     setup(cur, vb);
-    stage(cur, 0, 0);
-    const bool dyn = p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
+    stage(cur, cur.kb, 0);
+    const bool dyn = !SPLITK && p.queue != nullptr && ntiles > (int)gridDim.x;  // dynamic tile order (TileQueue)
     TileQueue tq;
     tq.init(p.queue, ntiles);
     int next_vb = vb + (int)gridDim.x;
@@ -1482,20 +1493,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
     ME_STAMP();
 
     while (true) {
-        const bool has_next = next_vb >= 0 && next_vb < ntiles;
+        const bool has_next = next_vb >= 0 && next_vb < nitems;
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int kt = 0; kt < nk; ++kt) {
+        const int kt_end = SPLITK ? cur.ke : nk;
+        for (int kt = SPLITK ? cur.kb : 0; kt < kt_end; ++kt) {
             ME_PHASE(-1);
-            if (kt + 1 < nk) {
+            if (kt + 1 < kt_end) {
                 stage(cur, kt + 1, buf ^ 1);
             } else if (has_next) {
                 setup(nxt, next_vb);
-                stage(nxt, 0, buf ^ 1);
+                stage(nxt, SPLITK ? nxt.kb : 0, buf ^ 1);
             }
             ME_PHASE(0);
             const char* sb = smem + buf * STAGE_BYTES;
@@ -1544,6 +1556,63 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_kernel(const GemmParams p
         // buf now holds the next tile's first slab; buf^1 was consumed last and is the scratch
         char* scratch0 = smem + (buf ^ 1) * STAGE_BYTES;
         int drawn = -1;  // lane 0 of wave 0: the tile after next
+        bool finish = true;
+        if constexpr (SPLITK) {
+            // the partial in accumulator layout: wave-instruction (i, j) of the workgroup writes NW KiB contiguously.
+            // Coherence as in resid_ln_epilogue: write-through stores and cache-bypassing loads at agent scope (sc1) instead of
+            // fences -- a release / acquire fence pair writes back and invalidates the XCD's whole L2 per workgroup, which made
+            // the split launches 2 - 3 x slower than the whole-K ones they replace.
+            constexpr int NT = NW * 64;
+            f32x4* part = reinterpret_cast<f32x4*>(p.splitk_ws) + (size_t)(cur.tile * S) * (MI * NI * NT) + tid;
+            f32x4* mine = part + (size_t)(vb - cur.tile * S) * (MI * NI * NT);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(mine + (i * NI + j) * NT), "v"(acc[i][j]) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its write-through stores ...
+            // (... whose data registers must stay untouched until then: dead after the asm for all the compiler knows, it took them
+            // for the next store's address one instruction later -- a wide store reads its data after issue)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" : : "v"(acc[i][j]));
+            __syncthreads();                                   // ... before ONE lane signals for the workgroup
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(p.splitk_cnt + cur.tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<volatile int*>(scratch0) = old == (unsigned)(S - 1);
+            }
+            __syncthreads();
+            finish = *reinterpret_cast<volatile int*>(scratch0) != 0;
+            __syncthreads();  // (the word is epilogue scratch from here on)
+            if (finish) {
+                if (tid == 0) __hip_atomic_store(p.splitk_cnt + cur.tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s2 = 0; s2 < S; ++s2) {  // split order, this item's own partial included
+                    f32x4 v[MI][NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1"
+                                         : "=v"(v[i][j])
+                                         : "v"(part + (size_t)s2 * (MI * NI * NT) + (i * NI + j) * NT)
+                                         : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            asm volatile("" : "+v"(v[i][j]));  // (the loads are invisible to the compiler's waitcnt pass: use behind the wait)
+                            acc[i][j] += v[i][j];
+                        }
+                }
+            }
+        }
+        if (finish)
         gemm_epilogue<T, EPI, MI, NI, TM, TN, MI_CH>(
             p, acc, cur.m0, cur.n0, wm, wn, lane, scratch0 + wave * (16 * MI_CH * (TN * 4)), [&]() {
                 if (dyn && has_next && tid == 0) drawn = tq.draw();
@@ -1990,10 +2059,10 @@ void gemm_launch_pp(const GemmParams& p, hipStream_t stream) {
     ME_HIP(hipGetLastError());
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI, bool SPLITK = false>
 void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, AMODE, EPI>;
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, AMODE, EPI, SPLITK>;
     static PerDeviceOnce once;  // workgroups that fit on the chip at once (per instantiation and device)
     const int resident = per_device_once(once, [&](int dev) {
         ME_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -2004,7 +2073,11 @@ void gemm_launch_cfg(const GemmParams& p, hipStream_t stream) {
         r -= r % 8;  // whole XCD rounds: workgroup b always lands on XCD b % 8
         return r < 8 ? 8 : r;
     });
-    const int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    int64_t ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    if constexpr (SPLITK) {
+        ME_CHECK(p.split_k > 1 && p.split_k <= p.K / 64 && p.splitk_ws && p.splitk_cnt, ME_ERR_BAD_ARG, "gemm: split-K %d of K = %d", p.split_k, p.K);
+        ntiles *= p.split_k;
+    }
     ME_CHECK(ntiles > 0 && ntiles < (1ll << 31), ME_ERR_BAD_SHAPE, "gemm grid %lld out of range",
              (long long)ntiles);
     const int64_t grid = ntiles < resident ? ntiles : resident;
@@ -2655,7 +2728,15 @@ void gemm_dispatch(const GemmParams& p, int cfg, hipStream_t stream);
     void gemm_dispatch<T, AMODE, EPI>(const GemmParams& p, int cfg, hipStream_t stream) { \
         switch (cfg) {                                                                    \
             case 0: gemm_launch_pp<T, 256, 256, 2, 4, AMODE, EPI>(p, stream); break;       \
-            case 1: gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
+            case 1:                                                                       \
+                if constexpr (EPI == EPI_STORE) {                                         \
+                    if (p.split_k > 1) {                                                  \
+                        gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI, true>(p, stream);  \
+                        break;                                                            \
+                    }                                                                     \
+                }                                                                         \
+                gemm_launch_cfg<T, 128, 128, 2, 2, AMODE, EPI>(p, stream);                \
+                break;                                                                    \
             case 2: gemm_launch_cfg<T, 64, 64, 2, 2, AMODE, EPI>(p, stream); break;       \
             case 3: gemm_launch_cfg<T, 160, 128, 2, 2, AMODE, EPI>(p, stream); break;     \
             case 4: gemm_launch_ring<T, 64, 64, 2, 2, 6, AMODE, EPI>(p, stream); break;    \

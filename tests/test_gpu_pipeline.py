@@ -711,6 +711,49 @@ def test_composed_features_equal_the_two_layers(tmp_path):
     assert frame_err < 3 * inner_err + 1e-3      # a missing border term would be of the order of the bias: 10 - 100 x this
 
 
+_SPLITK_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import matrix_eyes_amd as m
+from matrix_eyes_amd.synthetic import synthetic_checkpoint, synthetic_images
+cfg = m.ModelConfig.tiny()
+ctx = m.Context(0, "f16", cfg)
+ctx.load_state_dict(synthetic_checkpoint(cfg))
+rgb = synthetic_images(3, cfg.img_size, "structured", seed=11)
+d, fov = ctx.extract_depth(rgb, None, want_fov=True)
+again, fov2 = ctx.extract_depth(rgb, None, want_fov=True)     # the last arriver differs from run to run: the sum must not
+assert np.array_equal(d, again) and np.array_equal(fov, fov2)
+one, fov1 = ctx.extract_depth(rgb[1:2], None, want_fov=True)  # a batch is a loop of batch-one calls, bit for bit
+assert np.array_equal(one[0], d[1]) and fov1[0] == fov[1]
+np.save(sys.argv[2], d)
+"""
+
+
+def test_split_k_tail_launches_are_deterministic(tmp_path):
+    """The deep, small launches of the decoder / upsample tail as tile x K-range work items (gemm_core.h gemm_kernel<..., SPLITK>,
+    pipeline.hip maybe_split_k): every work item writes its f32 partial, the LAST arriver of a tile sums them in split order.
+    Opt-in (ME_SPLIT_K=1: it does not pay); the test lowers its K bound so that a tiny model has such launches.
+    Repeated runs and a batch against its images give the same bits (inside the child); against ME_SPLIT_K=0 only the order of
+    the f32 sums differs -- which moves 16-bit operand roundings downstream, so the two maps differ like any two correct 16-bit
+    evaluations do (the same bound as the fused LayerNorm against its stand-alone launches; test_extract_depth_tiny and the
+    full-size pairs hold the split form to the fp32 oracle)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("split", {"ME_SPLIT_K": "1", "ME_SPLIT_K_MINK": "1024"}), ("whole", {"ME_SPLIT_K": "0"})):
+        path = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _SPLITK_CHILD, root, path], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path)
+    a, b = outs["split"], outs["whole"]
+    err = rel_l2(a, b)
+    print("split-K against whole-K launches: rel-L2", err, "identical" if np.array_equal(a, b) else "")
+    assert np.isfinite(a).all() and 0 < err < 1.5e-3
+
+
 _LN_FALLBACK_CHILD = """
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
