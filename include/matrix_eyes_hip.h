@@ -103,11 +103,11 @@ typedef struct me_model_config {
                                rounding 2^-22 instead of 2^-11): 1 = encoder upsample / fuse convs
                                (encoder.rs:307-325), 2 = fusion deconv + out_conv (decoder.rs:95-101), 4 = head
                                (mod.rs:323-333), 8 = decoder.convs (decoder.rs:189-195).  me_default_config: 3
-                               (full-size depth error 7e-4 relative L2 against the fp32 reference; 0: 1.0e-3,
+                               (full-size depth error 7.5e-4 relative L2 against the fp32 reference; 0: 1.0e-3,
                                7: 5.8e-4, 15: 5.2e-4 -- DESIGN.md section 5) */
     int32_t fp8_linears;    /* ME_DTYPE_FP8 contexts only: bit mask of the ViT linears that run on MX fp8 -- 1 = qkv,
                                2 = proj, 4 = fc1, 8 = fc2 (vit.rs:60-62,74,120,122); the others stay on the 16-bit kernels.
-                               0 = the default ME_FP8_LINEARS_DEFAULT.  profiles/r03_fp8_mask_budget.txt has depth error and
+                               0 = the default ME_FP8_LINEARS_DEFAULT.  profiles/r05_fp8_mask_budget.txt has depth error and
                                time per step for each mask */
 } me_model_config;
 

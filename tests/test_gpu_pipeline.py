@@ -516,7 +516,7 @@ def test_extract_depth_full_size_fp8(full_oracle):
     block-scaled fp8 (e4m3 elements, one e8m0 scale per 32 K elements; 2x the 16-bit MFMA rate), everything else
     f16.  fp8 operands carry 3 significand bits, so this configuration is NOT held to north_star's 1e-3: its depth
     error against the fp32 oracle is reported here (and in DESIGN.md).  Each linear on fp8 costs ~4e-2 of relative L2
-    on its own and they add in quadrature (profiles/r03_fp8_mask_budget.txt: 6.9e-2 for the default three, 7.8e-2 for
+    on its own and they add in quadrature (profiles/r05_fp8_mask_budget.txt: 6.9e-2 for the default three, 7.8e-2 for
     all four) -- each e4m3 product carries ~5 % of noise, which the residual stream (LayerScale 0.05 - 0.2) dilutes
     over 24 blocks; random weights have no structure that would absorb it."""
     ctx = loaded_ctx("full", "fp8")
@@ -525,7 +525,7 @@ def test_extract_depth_full_size_fp8(full_oracle):
     rep = depth_error_report(got, ref)
     print("full-size fp8", rep, float(fov[0]), ref_fov)
     # measured 6.9e-2 with the default fp8_linears = 13 (qkv + fc1 + fc2; 7.8e-2 with proj on fp8 too,
-    # profiles/r03_fp8_mask_budget.txt): the bound is 1.3x that
+    # profiles/r05_fp8_mask_budget.txt): the bound is 1.3x that
     assert np.isfinite(got).all() and rep["rel_l2"] < 9.0e-2
     assert abs(float(fov[0]) - ref_fov) < 2.0
 
