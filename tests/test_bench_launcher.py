@@ -126,3 +126,23 @@ def test_eight_ranks_aggregate_like_the_contract_says(tmp_path):
     # 8 ranks x 8 images / 0.1805 s = 355 files/s: past the node's 178 -> the line explains its own plateau
     assert line["chain"]["at_ceiling"] and "bound by the host" in line["chain"]["note"]
     assert not bench.chain_ceiling_note(1, 36.7)["at_ceiling"] and "ranks at this per-GPU rate" in bench.chain_ceiling_note(1, 36.7)["note"]
+
+
+def test_calibration_object_restates_the_rate_for_the_reference_box():
+    """bench.py's `calibration`: the medians of the five passes, the reference box's rates, and `value_normalised` = value /
+    (0.8 x MFMA-loop ratio + 0.2 x copy ratio): a box exactly like the reference leaves the value alone, a box whose MFMA loop
+    is 5 % slower raises it by 1 / 0.96, and a dead calibration (zeros) gives None instead of a division by zero."""
+    ref = bench.CAL_REFERENCE
+    cal = {"mfma_tflops": ref["mfma_tflops"], "mfma_clock_ghz": 1.9, "copy_gbs": ref["copy_gbs"], "mfma_loop_ms": 22.0,
+           "copy_ms": 0.22, "cus": 256, "mfma_runs": [1.0, 2.0, 3.0, 4.0, 5.0], "copy_runs": [5.0, 4.0, 3.0, 2.0, 1.0]}
+    out = bench.calibration_object(cal, 44.0)
+    assert out["value_normalised"] == 44.0 and out["box_speed_vs_reference"] == 1.0
+    assert out["mfma_loop_tflops_passes"] == [1.0, 2.0, 3.0, 4.0, 5.0] and out["copy_gbs_passes"] == [5.0, 4.0, 3.0, 2.0, 1.0]
+    assert out["reference"]["mfma_tflops"] == ref["mfma_tflops"] and "calibrate.hip" in out["loops"]
+    slow = dict(cal, mfma_tflops=0.95 * ref["mfma_tflops"])
+    out = bench.calibration_object(slow, 44.0)
+    assert abs(out["box_speed_vs_reference"] - (bench.CAL_MFMA_SHARE * 0.95 + (1 - bench.CAL_MFMA_SHARE))) < 1e-4
+    assert abs(out["value_normalised"] - 44.0 / out["box_speed_vs_reference"]) < 1e-3
+    dead = dict(cal, mfma_tflops=0.0)
+    out = bench.calibration_object(dead, 44.0)
+    assert out["value_normalised"] is None and out["box_speed_vs_reference"] is None
